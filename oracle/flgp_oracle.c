@@ -1,0 +1,442 @@
+/*
+ * flgp_oracle.c -- CPU restatement of FLGP's graph-Laplacian / heat-kernel
+ * covariance construction path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * This file is the parity oracle for the HIP path in flgp_amd/csrc.  Only
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it;
+ * the product (libflgp_hip.so) never links, calls or falls back to it.
+ *
+ * PARITY UNPINNED: the reference (junhuihe2000/FLGP) ships no tests, golden
+ * vectors or fixtures for this path and cannot be built here (needs R, Rcpp,
+ * RcppEigen, RcppParallel, RSpectra; none present).  The restatement is pinned
+ * only by hand-derived known answers, algebraic invariants and an independent
+ * numpy/scipy restatement (oracle/flgp_oracle.py), see tests/.
+ *
+ * Every function cites the reference lines it restates (paths relative to the
+ * reference checkout).  All dense matrices are column-major (R / Eigen
+ * default), reals are IEEE binary64, indices are 0-based int32.
+ *
+ * Arithmetic contract (shared, by design, with the HIP kernels so that the two
+ * agree bit for bit where the domain allows it):
+ *   - compiled with -ffp-contract=off: no implicit fusing;
+ *   - dot products are explicit k-ascending FMA chains
+ *         acc = a0*b0;  acc = fma(a_k, b_k, acc)  (k = 1..d-1);
+ *   - everything else is one rounded IEEE operation per source operator,
+ *     evaluated left to right as written in the reference expression;
+ *   - k-NN ties: lower anchor index wins (the reference's std::partial_sort
+ *     leaves it unspecified, src/Utils.cpp:93).
+ * The reference's own summation order inside Eigen GEMM / packet reductions is
+ * unspecified, so agreement with it can only ever be to rounding level.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define FLGP_ORACLE_RMAX 64
+
+int flgp_oracle_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}
+
+/* k-ascending FMA chain; sa/sb are element strides. */
+static inline double dotf(const double *a, long sa, const double *b, long sb, int d) {
+  double acc = a[0] * b[0];
+  for (int k = 1; k < d; ++k) acc = fma(a[(long)k * sa], b[(long)k * sb], acc);
+  return acc;
+}
+
+/* ------------------------------------------------------------------------- *
+ * k-NN to anchors.  Restates KNN_cpp / KNN_Index, src/Utils.cpp:72-192:
+ *   D = ((-2 X_b U^T).colwise() + |x|^2).rowwise() + |u|^2   (src/Utils.cpp:121)
+ *   per row: indices of the r smallest D, ascending              (:91-94)
+ * D(i,j) = (fma(-2, <x_i,u_j>, |x_i|^2)) + |u_j|^2 ; the scaling by -2 is exact,
+ * so this equals ((-2 x).u + |x|^2) + |u|^2 of the reference expression.
+ * The batch size (100, src/Utils.h:62) affects nothing numerically.
+ * idx: n x r column-major (as Eigen::MatrixXi), dist (optional): n x r, the
+ * values D(i, idx(i,k)) that `output=true` stores in distances_sp (:162-167).
+ * ------------------------------------------------------------------------- */
+int flgp_oracle_knn(const double *X, int n, int d, const double *U, int s, int r,
+                    int *idx, double *dist) {
+  if (n < 0 || d <= 0 || s <= 0 || r <= 0 || r > s || r > FLGP_ORACLE_RMAX) return -1;
+  double *uu = (double *)malloc(sizeof(double) * (size_t)s);
+  if (!uu) return -2;
+  for (int j = 0; j < s; ++j) uu[j] = dotf(U + j, s, U + j, s, d);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; ++i) {
+    double bd[FLGP_ORACLE_RMAX];
+    int bi[FLGP_ORACLE_RMAX];
+    int cnt = 0;
+    const double xx = dotf(X + i, n, X + i, n, d);
+    for (int j = 0; j < s; ++j) {
+      const double dt = dotf(X + i, n, U + j, s, d);
+      const double D = fma(-2.0, dt, xx) + uu[j];
+      if (cnt < r) {
+        int p = cnt++;
+        while (p > 0 && D < bd[p - 1]) { bd[p] = bd[p - 1]; bi[p] = bi[p - 1]; --p; }
+        bd[p] = D; bi[p] = j;
+      } else if (D < bd[r - 1]) {
+        int p = r - 1;
+        while (p > 0 && D < bd[p - 1]) { bd[p] = bd[p - 1]; bi[p] = bi[p - 1]; --p; }
+        bd[p] = D; bi[p] = j;
+      }
+    }
+    for (int k = 0; k < r; ++k) {
+      idx[(size_t)k * n + i] = bi[k];
+      if (dist) dist[(size_t)k * n + i] = bd[k];
+    }
+  }
+  free(uu);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- *
+ * Euclidean projection onto the probability simplex.
+ * Restates v_to_z_cpp, src/lae.cpp:137-153.
+ * ------------------------------------------------------------------------- */
+static void v_to_z(const double *v, int r, double *z) {
+  double vd[FLGP_ORACLE_RMAX], cs[FLGP_ORACLE_RMAX];
+  for (int a = 0; a < r; ++a) vd[a] = v[a];
+  /* std::sort(..., std::greater) (:140): any correct sort yields the same array */
+  for (int a = 1; a < r; ++a) {
+    double t = vd[a]; int p = a;
+    while (p > 0 && vd[p - 1] < t) { vd[p] = vd[p - 1]; --p; }
+    vd[p] = t;
+  }
+  double c = 0.0;                                  /* std::partial_sum (:142) */
+  for (int a = 0; a < r; ++a) { c = (a == 0) ? vd[0] : c + vd[a]; cs[a] = c; }
+  int rho = r;                                     /* (:143-147) */
+  for (; rho > 0; --rho) {
+    double vstar = vd[rho - 1] - (cs[rho - 1] - 1.0) / (double)rho;
+    if (vstar > 0) break;
+  }
+  if (rho == 0) rho = 1;  /* unreachable for finite input: v_(1)-(v_(1)-1)/1 = 1 > 0 */
+  /* v_desc.head(rho).sum() (:149), defined here as the sequential partial sum */
+  const double theta = (cs[rho - 1] - 1.0) / (double)rho;
+  for (int a = 0; a < r; ++a) { double t = v[a] - theta; z[a] = t > 0.0 ? t : 0.0; }
+}
+
+int flgp_oracle_v_to_z(const double *v, int r, double *z) {
+  if (r <= 0 || r > FLGP_ORACLE_RMAX) return -1;
+  v_to_z(v, r, z);
+  return 0;
+}
+
+/* g(z) = |x - zU|^2 / 2   (src/lae.cpp:104,118) ; Ui is r x d, row-major here */
+static double half_sq_resid(const double *x, const double *Ui, const double *z, int r, int d) {
+  double acc = 0.0;
+  for (int k = 0; k < d; ++k) {
+    double zu = z[0] * Ui[k];
+    for (int a = 1; a < r; ++a) zu = fma(z[a], Ui[(size_t)a * d + k], zu);
+    const double df = x[k] - zu;
+    acc = (k == 0) ? df * df : fma(df, df, acc);
+  }
+  return acc / 2.0;
+}
+
+/* ------------------------------------------------------------------------- *
+ * Local anchor embedding of one point.
+ * Restates local_anchor_embedding_cpp, src/lae.cpp:76-133.
+ * x: d, Ui: r x d ROW-major (row a = a-th nearest anchor), z out: r.
+ * The inner backtracking loop is unbounded in the reference (:112-129); it is
+ * capped at 64 doublings here and in the HIP kernel (beta = 2^64 beta_c forces
+ * z = proj(v) and the test passes unless the data are NaN).
+ * Returns the number of outer iterations taken.
+ * ------------------------------------------------------------------------- */
+static int lae_point(const double *x, const double *Ui, int r, int d, double *zout) {
+  double G[FLGP_ORACLE_RMAX * FLGP_ORACLE_RMAX]; /* UUt (:90) */
+  double xUt[FLGP_ORACLE_RMAX];
+  double zp[FLGP_ORACLE_RMAX], zc[FLGP_ORACLE_RMAX], v[FLGP_ORACLE_RMAX], grad[FLGP_ORACLE_RMAX];
+  double vt[FLGP_ORACLE_RMAX], z[FLGP_ORACLE_RMAX], dz[FLGP_ORACLE_RMAX];
+  for (int a = 0; a < r; ++a) {
+    for (int b = 0; b < r; ++b) G[a * r + b] = dotf(Ui + (size_t)a * d, 1, Ui + (size_t)b * d, 1, d);
+    xUt[a] = dotf(x, 1, Ui + (size_t)a * d, 1, d);
+  }
+  const double z0 = 1.0 / (double)r;              /* (:82) */
+  for (int a = 0; a < r; ++a) zp[a] = zc[a] = z0;
+  double dp = 0.0, dc = 1.0, bc = 1.0;             /* (:83-84) */
+  const double tol = 1e-5; const int T = 100;      /* (:86) */
+  int t = 0;
+  for (; t < T; ++t) {
+    const double alpha = (dp - 1.0) / dc;          /* (:99) */
+    for (int a = 0; a < r; ++a) v[a] = zc[a] + alpha * (zc[a] - zp[a]);   /* (:101) */
+    const double g_v = half_sq_resid(x, Ui, v, r, d);                     /* (:103) */
+    for (int a = 0; a < r; ++a) {                  /* grad = v*UUt - x*Ut (:105) */
+      double acc = v[0] * G[a];
+      for (int b = 1; b < r; ++b) acc = fma(v[b], G[b * r + a], acc);
+      grad[a] = acc - xUt[a];
+    }
+    for (int j = 0;; ++j) {                        /* (:107-129) */
+      const double beta = ldexp(bc, j);            /* std::pow(2,j)*beta_curr (:110) */
+      const double ib = 1.0 / beta;
+      for (int a = 0; a < r; ++a) vt[a] = v[a] - ib * grad[a];            /* (:112) */
+      v_to_z(vt, r, z);                            /* (:114) */
+      const double g_z = half_sq_resid(x, Ui, z, r, d);                   /* (:116) */
+      for (int a = 0; a < r; ++a) dz[a] = z[a] - v[a];
+      const double gd = dotf(grad, 1, dz, 1, r);
+      const double sq = dotf(dz, 1, dz, 1, r);
+      const double g_t = (g_v + gd) + (beta * sq) / 2.0;                  /* (:117) */
+      if (g_z <= g_t || j >= 64) {
+        bc = beta;
+        for (int a = 0; a < r; ++a) { zp[a] = zc[a]; zc[a] = z[a]; }
+        break;
+      }
+    }
+    dp = dc;                                       /* (:127-128) */
+    dc = (1.0 + sqrt(1.0 + (4.0 * dc) * dc)) / 2.0;
+    for (int a = 0; a < r; ++a) dz[a] = zc[a] - zp[a];
+    if (dotf(dz, 1, dz, 1, r) < tol) { ++t; break; }                      /* (:130) */
+  }
+  for (int a = 0; a < r; ++a) zout[a] = zc[a];
+  return t;
+}
+
+/* x: d contiguous, U: r x d COLUMN-major (R matrix), as the R-visible
+ * local_anchor_embedding_cpp(x, U) takes them (src/RcppExports.cpp:434-443). */
+int flgp_oracle_lae_point(const double *x, int d, const double *U, int r, double *z) {
+  if (r <= 0 || r > FLGP_ORACLE_RMAX || d <= 0) return -1;
+  double *Ui = (double *)malloc(sizeof(double) * (size_t)r * d);
+  if (!Ui) return -2;
+  for (int a = 0; a < r; ++a)
+    for (int k = 0; k < d; ++k) Ui[(size_t)a * d + k] = U[(size_t)k * r + a];
+  int it = lae_point(x, Ui, r, d, z);
+  free(Ui);
+  return it;
+}
+
+/* ------------------------------------------------------------------------- *
+ * LAE_cpp, src/lae.cpp:48-70 + LAE_Parallel :15-45.
+ * knn_idx: n x r column-major k-NN indices (distance order).
+ * Output in ELL form with each row sorted by ascending column index, i.e. the
+ * inner order of the reference's row-major Eigen::SparseMatrix after the
+ * Z_sp.insert loop (:60-67); explicit zeros are kept.
+ *   ell_idx, ell_val: row-major n x r.
+ *   iters (optional): outer iteration count per point.
+ * ------------------------------------------------------------------------- */
+int flgp_oracle_lae(const double *X, int n, int d, const double *U, int s, int r,
+                    const int *knn_idx, int *ell_idx, double *ell_val, int *iters) {
+  if (r <= 0 || r > FLGP_ORACLE_RMAX || d <= 0 || r > s) return -1;
+  int err = 0;
+#pragma omp parallel
+  {
+    double *Ui = (double *)malloc(sizeof(double) * (size_t)r * d);
+    double *x = (double *)malloc(sizeof(double) * (size_t)d);
+    if (!Ui || !x) {
+#pragma omp atomic write
+      err = 1;
+    }
+#pragma omp barrier
+    if (!err) {
+#pragma omp for schedule(dynamic, 256)
+      for (int i = 0; i < n; ++i) {
+        double z[FLGP_ORACLE_RMAX];
+        int id[FLGP_ORACLE_RMAX];
+        for (int k = 0; k < d; ++k) x[k] = X[(size_t)k * n + i];
+        for (int a = 0; a < r; ++a) {
+          id[a] = knn_idx[(size_t)a * n + i];
+          for (int k = 0; k < d; ++k) Ui[(size_t)a * d + k] = U[(size_t)k * s + id[a]]; /* mat_indexing, src/Utils.h:130-137 */
+        }
+        int it = lae_point(x, Ui, r, d, z);
+        if (iters) iters[i] = it;
+        /* sort (id, z) by id ascending = CSR inner order */
+        for (int a = 1; a < r; ++a) {
+          int ti = id[a]; double tz = z[a]; int p = a;
+          while (p > 0 && id[p - 1] > ti) { id[p] = id[p - 1]; z[p] = z[p - 1]; --p; }
+          id[p] = ti; z[p] = tz;
+        }
+        for (int a = 0; a < r; ++a) { ell_idx[(size_t)i * r + a] = id[a]; ell_val[(size_t)i * r + a] = z[a]; }
+      }
+    }
+    free(Ui); free(x);
+  }
+  return err ? -2 : 0;
+}
+
+/* ------------------------------------------------------------------------- *
+ * SE similarity weights: Z = exp(-dist/(4 eps^2)) on the stored k-NN entries.
+ * Restates cross_similarity_se_cpp, src/Spectrum.cpp:126-132.
+ * knn_idx/knn_dist n x r column-major -> ELL sorted by column.
+ * ------------------------------------------------------------------------- */
+int flgp_oracle_se_weights(const int *knn_idx, const double *knn_dist, int n, int r,
+                           double epsilon, int *ell_idx, double *ell_val) {
+  if (r <= 0 || r > FLGP_ORACLE_RMAX) return -1;
+  const double den = (4.0 * epsilon) * epsilon;
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; ++i) {
+    int id[FLGP_ORACLE_RMAX]; double z[FLGP_ORACLE_RMAX];
+    for (int a = 0; a < r; ++a) {
+      id[a] = knn_idx[(size_t)a * n + i];
+      z[a] = exp(-knn_dist[(size_t)a * n + i] / den);
+    }
+    for (int a = 1; a < r; ++a) {
+      int ti = id[a]; double tz = z[a]; int p = a;
+      while (p > 0 && id[p - 1] > ti) { id[p] = id[p - 1]; z[p] = z[p - 1]; --p; }
+      id[p] = ti; z[p] = tz;
+    }
+    for (int a = 0; a < r; ++a) { ell_idx[(size_t)i * r + a] = id[a]; ell_val[(size_t)i * r + a] = z[a]; }
+  }
+  return 0;
+}
+
+/* column sums in row-ascending order: RowVectorXd::Ones(n) * Z on a row-major
+ * sparse Z visits rows in order (src/Utils.cpp:200,203; src/Spectrum.cpp:149) */
+int flgp_oracle_colsum(const int *ell_idx, const double *ell_val, int n, int s, int r, double *colsum) {
+  for (int j = 0; j < s; ++j) colsum[j] = 0.0;
+  for (size_t e = 0; e < (size_t)n * r; ++e) {
+    int j = ell_idx[e];
+    if (j < 0 || j >= s) return -1;
+    colsum[j] += ell_val[e];
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- *
+ * graphLaplacian_cpp, src/Utils.cpp:195-212.
+ * gl: 0 = "rw", 1 = "normalized", 2 = "cluster-normalized".
+ * In place on ell_val.  num_class: s cluster sizes (gl == 2 only).
+ * ------------------------------------------------------------------------- */
+int flgp_oracle_graph_laplacian(const int *ell_idx, double *ell_val, int n, int s, int r,
+                                int gl, const double *num_class) {
+  if (gl < 0 || gl > 2) return -3;   /* Rcpp::stop, src/Utils.cpp:207 */
+  if (gl == 2 && !num_class) return -4;
+  if (gl >= 1) {
+    double *c = (double *)malloc(sizeof(double) * (size_t)s);
+    if (!c) return -2;
+    int rc = flgp_oracle_colsum(ell_idx, ell_val, n, s, r, c);
+    if (rc) { free(c); return rc; }
+    for (int j = 0; j < s; ++j) c[j] = 1.0 / (c[j] + 1e-9);              /* (:201,204) */
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i)
+      for (int a = 0; a < r; ++a) {
+        size_t e = (size_t)i * r + a;
+        double v = ell_val[e] * c[ell_idx[e]];
+        if (gl == 2) v = v * num_class[ell_idx[e]];                       /* (:205) */
+        ell_val[e] = v;
+      }
+    free(c);
+  }
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; ++i) {                                           /* (:210-211) */
+    double rs = 0.0;
+    for (int a = 0; a < r; ++a) rs += ell_val[(size_t)i * r + a];         /* ascending column order */
+    const double inv = 1.0 / (rs + 1e-9);
+    for (int a = 0; a < r; ++a) ell_val[(size_t)i * r + a] = inv * ell_val[(size_t)i * r + a];
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- *
+ * A = Z diag(1/sqrt(|colsum|+1e-9)), src/Spectrum.cpp:149-150.
+ * In place; colsum_out (optional) receives the column sums of Z.
+ * ------------------------------------------------------------------------- */
+int flgp_oracle_scale_A(const int *ell_idx, double *ell_val, int n, int s, int r, double *colsum_out) {
+  double *c = (double *)malloc(sizeof(double) * (size_t)s);
+  if (!c) return -2;
+  int rc = flgp_oracle_colsum(ell_idx, ell_val, n, s, r, c);
+  if (rc) { free(c); return rc; }
+  if (colsum_out) memcpy(colsum_out, c, sizeof(double) * (size_t)s);
+  for (int j = 0; j < s; ++j) c[j] = 1.0 / sqrt(fabs(c[j]) + 1e-9);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; ++i)
+    for (int a = 0; a < r; ++a) { size_t e = (size_t)i * r + a; ell_val[e] = ell_val[e] * c[ell_idx[e]]; }
+  free(c);
+  return 0;
+}
+
+/* Gram matrix G = A^T A (s x s, symmetric) of the ELL matrix A, accumulated in
+ * row-ascending order with one rounded product and one rounded add per term.
+ * This is the s x s operator whose top-K eigenpairs RSpectra::svds iterates on
+ * (src/TruncatedSVD.cpp:23-28, src/Spectrum.h:105-106). */
+int flgp_oracle_gram(const int *ell_idx, const double *ell_val, int n, int s, int r, double *G) {
+  memset(G, 0, sizeof(double) * (size_t)s * s);
+#pragma omp parallel
+  {
+    int nt = 1, tid = 0;
+#ifdef _OPENMP
+    nt = omp_get_num_threads(); tid = omp_get_thread_num();
+#endif
+    const int lo = (int)((long)s * tid / nt), hi = (int)((long)s * (tid + 1) / nt);
+    for (int i = 0; i < n; ++i) {
+      const int *id = ell_idx + (size_t)i * r; const double *va = ell_val + (size_t)i * r;
+      for (int a = 0; a < r; ++a) {
+        const int ja = id[a];
+        if (ja < lo || ja >= hi) continue;
+        double *Grow = G + (size_t)ja * s;
+        for (int b = 0; b < r; ++b) Grow[id[b]] += va[a] * va[b];
+      }
+    }
+  }
+  return 0;
+}
+
+/* y = A x (n) and y = A^T x (s) for the ELL matrix: the two halves of the
+ * implicit operator x -> A^T (A x) that svds iterates on. */
+void flgp_oracle_ell_matvec(const int *ell_idx, const double *ell_val, int n, int r, const double *x, double *y) {
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; ++i) {
+    double acc = 0.0;
+    for (int a = 0; a < r; ++a) acc += ell_val[(size_t)i * r + a] * x[ell_idx[(size_t)i * r + a]];
+    y[i] = acc;
+  }
+}
+
+/* ------------------------------------------------------------------------- *
+ * Left singular vectors from right ones: u_k = A v_k / sigma_k, then the
+ * sqrt(n) scaling of spectrum_from_Z_cpp (src/Spectrum.cpp:157-158).
+ * V: s x K column-major (right singular vectors), sigma: K.
+ * vectors out: n x K column-major.
+ * ------------------------------------------------------------------------- */
+int flgp_oracle_u_recover(const int *ell_idx, const double *ell_val, int n, int s, int r,
+                          const double *V, const double *sigma, int K, double *vectors) {
+  const double sn = sqrt((double)n);
+#pragma omp parallel for schedule(static)
+  for (int i = 0; i < n; ++i) {
+    const int *id = ell_idx + (size_t)i * r; const double *va = ell_val + (size_t)i * r;
+    for (int k = 0; k < K; ++k) {
+      const double *Vk = V + (size_t)k * s;
+      double acc = 0.0;
+      for (int a = 0; a < r; ++a) acc += va[a] * Vk[id[a]];
+      vectors[(size_t)k * n + i] = (acc / sigma[k]) * sn;
+    }
+  }
+  return 0;
+}
+
+/* ------------------------------------------------------------------------- *
+ * HK_from_spectrum_cpp, src/Spectrum.cpp:83-94:
+ *   H(a,b) = sum_k V(idx0[a],k) exp(-t (1 - values_k)) V(idx1[b],k)
+ * vectors: n x ldk... column-major with leading dimension n; H: n0 x n1.
+ * ------------------------------------------------------------------------- */
+int flgp_oracle_hk(const double *values, const double *vectors, int n, int K, double t,
+                   const int *idx0, int n0, const int *idx1, int n1, double *H) {
+  double *w = (double *)malloc(sizeof(double) * (size_t)K);
+  double *V1 = (double *)malloc(sizeof(double) * (size_t)n1 * K); /* V1[b*K+k] = w_k V(idx1[b],k) */
+  if (!w || !V1) { free(w); free(V1); return -2; }
+  for (int k = 0; k < K; ++k) w[k] = exp(-t * (1.0 - values[k]));
+  for (int b = 0; b < n1; ++b) {
+    if (idx1[b] < 0 || idx1[b] >= n) { free(w); free(V1); return -1; }
+    for (int k = 0; k < K; ++k) V1[(size_t)b * K + k] = vectors[(size_t)k * n + idx1[b]] * w[k];
+  }
+  int bad = 0;
+#pragma omp parallel
+  {
+    double *v0 = (double *)malloc(sizeof(double) * (size_t)K);
+#pragma omp for schedule(static)
+    for (int a = 0; a < n0; ++a) {
+      const int ia = idx0[a];
+      if (ia < 0 || ia >= n || !v0) { bad = 1; continue; }
+      for (int k = 0; k < K; ++k) v0[k] = vectors[(size_t)k * n + ia];   /* mat_indexing gather */
+      for (int b = 0; b < n1; ++b) H[(size_t)b * n0 + a] = dotf(v0, 1, V1 + (size_t)b * K, 1, K);
+    }
+    free(v0);
+  }
+  free(w); free(V1);
+  return bad ? -1 : 0;
+}

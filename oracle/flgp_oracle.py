@@ -1,0 +1,407 @@
+"""CPU parity oracle for the FLGP heat-kernel covariance path -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+module; the product package (flgp_amd) never does and fails loudly without its HIP
+library instead of falling back to anything in here.
+
+PARITY UNPINNED: the reference ships no tests or golden vectors for this path and cannot
+be built in this image (no R / Rcpp / RcppEigen / RcppParallel / RSpectra).  What pins
+this oracle: hand-derived known answers, algebraic invariants and the two independent
+restatements in this file checking each other (C via ctypes, and pure numpy).
+
+Two layers:
+  * ``C``  -- ctypes bindings to oracle/libflgp_oracle.so (flgp_oracle.c): the fast,
+    multi-threaded restatement whose arithmetic order the HIP kernels share.
+  * ``np_*`` -- a second, independent restatement in plain numpy / Python loops written
+    from SURVEY.md Appendix A; used on small cases to check the C code, and to produce
+    the fixtures under tests/golden (tests/golden/make_golden.py).
+
+The truncated SVD (src/TruncatedSVD.cpp:9-34) is third-party arithmetic: the reference
+calls RSpectra::svds (Spectra's implicitly restarted Lanczos on the s x s operator
+A^T A, tol 1e-10, ncv = max(2K+1, 20); version unpinned, source not in /root/reference)
+or Eigen::BDCSVD when K == s.  Restated here with the same algorithm families from
+scipy: ARPACK's implicitly restarted Lanczos (``scipy.sparse.linalg.svds``) and LAPACK's
+divide-and-conquer SVD (``numpy.linalg.svd``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libflgp_oracle.so")
+
+GL_CODES = {"rw": 0, "normalized": 1, "cluster-normalized": 2}
+
+
+def build(force: bool = False) -> str:
+    """Compile flgp_oracle.c with gcc (oracle/Makefile)."""
+    src = os.path.join(_HERE, "flgp_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B", "libflgp_oracle.so"], check=True,
+                       stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = ctypes.CDLL(_SO)
+        dp = ctypes.POINTER(ctypes.c_double)
+        ip = ctypes.POINTER(ctypes.c_int)
+        ci, cd = ctypes.c_int, ctypes.c_double
+        L.flgp_oracle_threads.restype = ci
+        L.flgp_oracle_knn.argtypes = [dp, ci, ci, dp, ci, ci, ip, dp]
+        L.flgp_oracle_v_to_z.argtypes = [dp, ci, dp]
+        L.flgp_oracle_lae_point.argtypes = [dp, ci, dp, ci, dp]
+        L.flgp_oracle_lae.argtypes = [dp, ci, ci, dp, ci, ci, ip, ip, dp, ip]
+        L.flgp_oracle_se_weights.argtypes = [ip, dp, ci, ci, cd, ip, dp]
+        L.flgp_oracle_colsum.argtypes = [ip, dp, ci, ci, ci, dp]
+        L.flgp_oracle_graph_laplacian.argtypes = [ip, dp, ci, ci, ci, ci, dp]
+        L.flgp_oracle_scale_A.argtypes = [ip, dp, ci, ci, ci, dp]
+        L.flgp_oracle_gram.argtypes = [ip, dp, ci, ci, ci, dp]
+        L.flgp_oracle_ell_matvec.argtypes = [ip, dp, ci, ci, dp, dp]
+        L.flgp_oracle_ell_matvec.restype = None
+        L.flgp_oracle_u_recover.argtypes = [ip, dp, ci, ci, ci, dp, dp, ci, dp]
+        L.flgp_oracle_hk.argtypes = [dp, dp, ci, ci, cd, ip, ci, ip, ci, dp]
+        _lib = L
+    return _lib
+
+
+def threads() -> int:
+    return int(lib().flgp_oracle_threads())
+
+
+def _d(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_double)) if a is not None else None
+
+
+def _i(a):
+    return a.ctypes.data_as(ctypes.POINTER(ctypes.c_int)) if a is not None else None
+
+
+def _f64(a):
+    return np.asfortranarray(np.asarray(a, dtype=np.float64))
+
+
+def _check(rc, what):
+    if rc < 0:
+        raise RuntimeError(f"oracle {what} failed with code {rc}")
+
+
+# ----------------------------------------------------------------------------------
+# C-backed restatement
+# ----------------------------------------------------------------------------------
+def knn(X, U, r, output=False):
+    """KNN_cpp (src/Utils.cpp:102-192). Returns ind_knn (n x r, 0-based) [, dist (n x r)]."""
+    X = _f64(X); U = _f64(U)
+    n, d = X.shape; s = U.shape[0]
+    assert U.shape[1] == d
+    idx = np.zeros((n, r), dtype=np.int32, order="F")
+    dist = np.zeros((n, r), dtype=np.float64, order="F") if output else None
+    _check(lib().flgp_oracle_knn(_d(X), n, d, _d(U), s, r, _i(idx), _d(dist)), "knn")
+    return (idx, dist) if output else idx
+
+
+def v_to_z(v):
+    """v_to_z_cpp (src/lae.cpp:137-153)."""
+    v = np.ascontiguousarray(v, dtype=np.float64).ravel()
+    z = np.zeros_like(v)
+    _check(lib().flgp_oracle_v_to_z(_d(v), v.size, _d(z)), "v_to_z")
+    return z
+
+
+def local_anchor_embedding(x, U):
+    """local_anchor_embedding_cpp(x, U) (src/lae.cpp:76-133); U is r x d."""
+    x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+    U = _f64(U)
+    r, d = U.shape
+    z = np.zeros(r)
+    _check(lib().flgp_oracle_lae_point(_d(x), d, _d(U), r, _d(z)), "lae_point")
+    return z
+
+
+def lae(X, U, r, knn_idx=None, return_iters=False):
+    """LAE_cpp (src/lae.cpp:48-70) -> ELL (idx n x r, val n x r; rows sorted by column)."""
+    X = _f64(X); U = _f64(U)
+    n, d = X.shape; s = U.shape[0]
+    if knn_idx is None:
+        knn_idx = knn(X, U, r)
+    knn_idx = np.asfortranarray(knn_idx, dtype=np.int32)
+    eidx = np.zeros((n, r), dtype=np.int32)
+    eval_ = np.zeros((n, r), dtype=np.float64)
+    iters = np.zeros(n, dtype=np.int32)
+    _check(lib().flgp_oracle_lae(_d(X), n, d, _d(U), s, r, _i(knn_idx), _i(eidx), _d(eval_), _i(iters)), "lae")
+    return (eidx, eval_, iters) if return_iters else (eidx, eval_)
+
+
+def se_weights(knn_idx, knn_dist, epsilon):
+    """exp(-dist/(4 eps^2)) on the stored entries (src/Spectrum.cpp:126-132) -> ELL."""
+    knn_idx = np.asfortranarray(knn_idx, dtype=np.int32)
+    knn_dist = _f64(knn_dist)
+    n, r = knn_idx.shape
+    eidx = np.zeros((n, r), dtype=np.int32)
+    eval_ = np.zeros((n, r), dtype=np.float64)
+    _check(lib().flgp_oracle_se_weights(_i(knn_idx), _d(knn_dist), n, r, float(epsilon), _i(eidx), _d(eval_)), "se")
+    return eidx, eval_
+
+
+def colsum(eidx, eval_, s):
+    n, r = eidx.shape
+    c = np.zeros(s)
+    _check(lib().flgp_oracle_colsum(_i(eidx), _d(eval_), n, s, r, _d(c)), "colsum")
+    return c
+
+
+def graph_laplacian(eidx, eval_, s, gl, num_class=None):
+    """graphLaplacian_cpp (src/Utils.cpp:195-212). Returns a new val array."""
+    if gl not in GL_CODES:
+        raise ValueError("Error: the type of graph Laplacian is not supported!")
+    n, r = eidx.shape
+    out = np.array(eval_, dtype=np.float64, order="C", copy=True)
+    nc = None if num_class is None else np.ascontiguousarray(num_class, dtype=np.float64)
+    _check(lib().flgp_oracle_graph_laplacian(_i(eidx), _d(out), n, s, r, GL_CODES[gl], _d(nc)), "graph_laplacian")
+    return out
+
+
+def scale_A(eidx, eval_, s):
+    """A = Z diag(1/sqrt(|colsum|+1e-9)) (src/Spectrum.cpp:149-150). Returns (A_val, colsum)."""
+    n, r = eidx.shape
+    out = np.array(eval_, dtype=np.float64, order="C", copy=True)
+    c = np.zeros(s)
+    _check(lib().flgp_oracle_scale_A(_i(eidx), _d(out), n, s, r, _d(c)), "scale_A")
+    return out, c
+
+
+def gram(eidx, aval, s):
+    n, r = eidx.shape
+    G = np.zeros((s, s))
+    _check(lib().flgp_oracle_gram(_i(eidx), _d(aval), n, s, r, _d(G)), "gram")
+    return G
+
+
+def u_recover(eidx, aval, s, V, sigma):
+    n, r = eidx.shape
+    V = _f64(V); K = V.shape[1]
+    sigma = np.ascontiguousarray(sigma, dtype=np.float64)
+    out = np.zeros((n, K), order="F")
+    _check(lib().flgp_oracle_u_recover(_i(eidx), _d(aval), n, s, r, _d(V), _d(sigma), K, _d(out)), "u_recover")
+    return out
+
+
+def ell_to_csr(eidx, eval_, s):
+    import scipy.sparse as sp
+    n, r = eidx.shape
+    indptr = np.arange(0, n * r + 1, r, dtype=np.int64)
+    return sp.csr_matrix((eval_.ravel(), eidx.ravel(), indptr), shape=(n, s))
+
+
+def truncated_svd(eidx, aval, s, K, method="auto", seed=0):
+    """truncated_SVD_cpp (src/TruncatedSVD.cpp:9-34): returns (values = sigma^2 desc, U n x K).
+
+    method: 'dense' -> LAPACK SVD of the densified A (the K == s BDCSVD branch, :17-20);
+            'svds'  -> ARPACK implicitly restarted Lanczos on A^T A (the RSpectra::svds
+                       branch, :23-30; tol 1e-10, ncv = max(2K+1, 20) as Spectra's defaults);
+            'gram'  -> dense symmetric eigendecomposition of the C-built Gram matrix, then
+                       u = A v / sigma: the route the HIP path takes, kept here so tests can
+                       separate "route" differences from kernel bugs;
+            'auto'  -> 'dense' if K == s else 'svds'.
+    """
+    n, r = eidx.shape
+    if K < 0:
+        K = s
+    if method == "auto":
+        method = "dense" if K == s else "svds"
+    if method == "dense":
+        A = ell_to_csr(eidx, aval, s).toarray()
+        Uu, sv, _ = np.linalg.svd(A, full_matrices=False)
+        return (sv[:K] ** 2).copy(), np.asfortranarray(Uu[:, :K])
+    if method == "svds":
+        from scipy.sparse.linalg import svds
+        A = ell_to_csr(eidx, aval, s).tocsc()
+        ncv = min(s, max(2 * K + 1, 20))
+        v0 = np.random.default_rng(seed).standard_normal(min(n, s))
+        Uu, sv, _ = svds(A, k=K, ncv=ncv, tol=1e-10, which="LM", v0=v0, maxiter=1000 * s,
+                         return_singular_vectors="u")
+        order = np.argsort(-sv, kind="stable")
+        return (sv[order] ** 2).copy(), np.asfortranarray(Uu[:, order])
+    if method == "gram":
+        G = gram(eidx, aval, s)
+        w, V = np.linalg.eigh(G)
+        w = w[::-1][:K].copy(); V = V[:, ::-1][:, :K]
+        sig = np.sqrt(np.maximum(w, 0.0))
+        Uu = u_recover(eidx, aval, s, V, sig) / np.sqrt(float(n))
+        return w, np.asfortranarray(Uu)
+    raise ValueError(method)
+
+
+def spectrum_from_Z(eidx, zval, s, K, root=False, method="auto"):
+    """spectrum_from_Z_cpp (src/Spectrum.cpp:146-161) -> (values K, vectors n x K)."""
+    n = eidx.shape[0]
+    aval, _ = scale_A(eidx, zval, s)
+    values, Uu = truncated_svd(eidx, aval, s, K, method=method)
+    if root:
+        values = np.sqrt(values)
+    return values, np.asfortranarray(Uu * np.sqrt(float(n)))
+
+
+def hk_from_spectrum(values, vectors, K, t, idx0, idx1):
+    """HK_from_spectrum_cpp (src/Spectrum.cpp:83-94)."""
+    vectors = _f64(vectors)
+    n = vectors.shape[0]
+    values = np.ascontiguousarray(values[:K], dtype=np.float64)
+    idx0 = np.ascontiguousarray(idx0, dtype=np.int32); idx1 = np.ascontiguousarray(idx1, dtype=np.int32)
+    H = np.zeros((idx0.size, idx1.size), order="F")
+    _check(lib().flgp_oracle_hk(_d(values), _d(vectors), n, K, float(t), _i(idx0), idx0.size,
+                                _i(idx1), idx1.size, _d(H)), "hk")
+    return H
+
+
+def cross_similarity(X, U, r, gl="rw", kernel="lae", epsilon=0.1):
+    """cross_similarity_lae_cpp / cross_similarity_se_cpp (src/Spectrum.cpp:101-142).
+
+    U is s x d, or s x (d+1) with cluster sizes in the last column.  Returns ELL (idx, val).
+    """
+    X = _f64(X); U = _f64(U)
+    d = X.shape[1]; s = U.shape[0]
+    Ud = np.asfortranarray(U[:, :d])
+    if gl == "cluster-normalized":
+        if U.shape[1] < d + 1:
+            raise ValueError("cluster-normalized needs cluster sizes in column d of U")
+        num_class = np.ascontiguousarray(U[:, d])
+    else:
+        num_class = None
+    if kernel == "lae":
+        eidx, zval = lae(X, Ud, r)
+    elif kernel == "se":
+        kidx, kdist = knn(X, Ud, r, output=True)
+        eidx, zval = se_weights(kidx, kdist, epsilon)
+    else:
+        raise ValueError("The kernel type is not supported!")
+    return eidx, graph_laplacian(eidx, zval, s, gl, num_class)
+
+
+def heat_kernel_spectrum(X_all, U, r, K, kernel="lae", gl="rw", root=False, epsilon=0.1, method="auto"):
+    """heat_kernel_spectrum_cpp (src/Spectrum.cpp:48-76) with the anchors U given
+    (subsample_cpp, src/Utils.cpp:32-68, is outside the path: it calls R's kmeans)."""
+    s = U.shape[0]
+    if K < 0:
+        K = s
+    eidx, zval = cross_similarity(X_all, U, r, gl=gl, kernel=kernel, epsilon=epsilon)
+    return spectrum_from_Z(eidx, zval, s, K, root=root, method=method)
+
+
+def heat_kernel_covariance(X, X_new, U, r, t, K=-1, kernel="lae", gl="cluster-normalized", root=True,
+                           epsilon=0.1, method="auto"):
+    """heat_kernel_covariance_cpp (src/Spectrum.cpp:28-43) with the anchors given;
+    defaults are the R wrapper's (R/Fit.R:760-770)."""
+    X = _f64(X); X_new = _f64(X_new)
+    m = X.shape[0]
+    X_all = np.asfortranarray(np.vstack([X, X_new]))
+    n = X_all.shape[0]
+    s = U.shape[0]
+    if K < 0:
+        K = s
+    values, vectors = heat_kernel_spectrum(X_all, U, r, K, kernel, gl, root, epsilon, method)
+    return hk_from_spectrum(values, vectors, K, t, np.arange(n, dtype=np.int32), np.arange(m, dtype=np.int32))
+
+
+# ----------------------------------------------------------------------------------
+# Independent numpy restatement (small cases only; written from SURVEY.md Appendix A)
+# ----------------------------------------------------------------------------------
+def np_knn(X, U, r):
+    """A.1 in vectorised numpy: rounding may differ from the FMA chain in the last ulp, so
+    compare index sets on tie-free data, and distances to ~1e-12."""
+    X = np.asarray(X, float); U = np.asarray(U, float)
+    D = ((-2.0 * X) @ U.T + (X * X).sum(1)[:, None]) + (U * U).sum(1)[None, :]
+    idx = np.argsort(D, axis=1, kind="stable")[:, :r]
+    return idx.astype(np.int32), np.take_along_axis(D, idx, axis=1)
+
+
+def np_v_to_z(v):
+    v = np.asarray(v, float)
+    r = v.size
+    vd = np.sort(v)[::-1]
+    cs = np.cumsum(vd)
+    vstar = vd - (cs - 1.0) / np.arange(1, r + 1)
+    rho = r
+    while rho > 0 and not vstar[rho - 1] > 0:
+        rho -= 1
+    theta = (vd[:rho].sum() - 1.0) / rho
+    return np.maximum(v - theta, 0.0)
+
+
+def np_lae_point(x, Ui, max_backtrack=64):
+    """A.2 with numpy reductions (x: d, Ui: r x d)."""
+    x = np.asarray(x, float); Ui = np.asarray(Ui, float)
+    r = Ui.shape[0]
+    Ut = Ui.T
+    UUt = Ui @ Ut
+    z_prev = np.full(r, 1.0 / r); z_curr = z_prev.copy()
+    dp, dc, bc = 0.0, 1.0, 1.0
+    for _ in range(100):
+        alpha = (dp - 1.0) / dc
+        v = z_curr + alpha * (z_curr - z_prev)
+        g_v = ((x - v @ Ui) ** 2).sum() / 2.0
+        grad = v @ UUt - x @ Ut
+        j = 0
+        while True:
+            beta = (2.0 ** j) * bc
+            z = np_v_to_z(v - 1.0 / beta * grad)
+            g_z = ((x - z @ Ui) ** 2).sum() / 2.0
+            g_t = g_v + grad @ (z - v) + beta * ((z - v) ** 2).sum() / 2.0
+            if g_z <= g_t or j >= max_backtrack:
+                bc = beta; z_prev = z_curr; z_curr = z
+                break
+            j += 1
+        dp, dc = dc, (1.0 + np.sqrt(1.0 + 4.0 * dc * dc)) / 2.0
+        if ((z_curr - z_prev) ** 2).sum() < 1e-5:
+            break
+    return z_curr
+
+
+def np_lae_dense(X, U, r):
+    """LAE_cpp as a dense n x s matrix."""
+    X = np.asarray(X, float); U = np.asarray(U, float)
+    idx, _ = np_knn(X, U, r)
+    Z = np.zeros((X.shape[0], U.shape[0]))
+    for i in range(X.shape[0]):
+        Z[i, idx[i]] = np_lae_point(X[i], U[idx[i]])
+    return Z, idx
+
+
+def np_graph_laplacian_dense(Z, gl, num_class=None):
+    Z = np.array(Z, float)
+    if gl == "rw":
+        pass
+    elif gl in ("normalized", "cluster-normalized"):
+        Z = Z * (1.0 / (Z.sum(0) + 1e-9))[None, :]
+        if gl == "cluster-normalized":
+            Z = Z * np.asarray(num_class, float)[None, :]
+    else:
+        raise ValueError("Error: the type of graph Laplacian is not supported!")
+    return (1.0 / (Z.sum(1) + 1e-9))[:, None] * Z
+
+
+def np_spectrum_dense(Z, K, root=False):
+    """A.6 by LAPACK SVD of the dense A."""
+    n = Z.shape[0]
+    A = Z * (1.0 / np.sqrt(np.abs(Z.sum(0)) + 1e-9))[None, :]
+    Uu, sv, _ = np.linalg.svd(A, full_matrices=False)
+    vals = sv[:K] ** 2
+    if root:
+        vals = np.sqrt(vals)
+    return vals, Uu[:, :K] * np.sqrt(float(n))
+
+
+def np_hk(values, vectors, K, t, idx0, idx1):
+    w = np.exp(-t * (1.0 - np.asarray(values)[:K]))
+    return (vectors[idx0, :K] * w[None, :]) @ vectors[idx1, :K].T
