@@ -1,0 +1,263 @@
+"""Host-side mirror of FLGP's R-visible interface for the heat-kernel covariance path.
+
+R is not available in this image, so the layer FLGP users see (``R/RcppExports.R`` +
+``R/Fit.R:760-770``) is mirrored here in Python with the same function names, argument
+names, defaults and error behaviour, each call going straight through the C ABI of
+``libflgp_hip.so`` (``include/flgp_hip.h``) -- the same entry points the R ``.Call`` shim
+binds (``flgp_amd/csrc/rshim/flgp_rcall.c``).  Nothing here computes: numpy
+arrays are R's column-major matrices, scipy CSR matrices stand in for ``Matrix::dgRMatrix``.
+
+Anchors: ``subsample_cpp`` (reference src/Utils.cpp:32-68) is R's ``stats::kmeans`` /
+``ClusterR`` / ``sample`` and is outside the accelerated path.  Functions that subsample
+inside the reference take the anchors through the extra keyword ``U`` (s x d, or s x (d+1)
+with cluster sizes in the last column); ``subsample="random"`` is also provided (seeded
+numpy RNG in place of R's).
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import _lib
+from ._lib import FlgpError, check  # noqa: F401
+
+_DEFAULT_MODELS_CPP = dict(subsample="kmeans", kernel="lae", gl="rw", root=False)          # src/Spectrum.h:53-59
+_DEFAULT_MODELS_R = dict(subsample="kmeans", kernel="lae", gl="cluster-normalized", root=True)  # R/Fit.R:761-764
+
+
+def _f64(a, name="matrix"):
+    a = np.asarray(a, dtype=np.float64)
+    if a.ndim == 1:
+        a = a.reshape(-1, 1)
+    if a.ndim != 2:
+        raise ValueError(f"{name} must be a matrix")
+    return np.asfortranarray(a)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data
+
+
+def _b(s):
+    return str(s).encode("utf-8")
+
+
+@dataclass
+class EigenPair:
+    """``EigenPair`` (reference src/Spectrum.h:117-124): eigenvalues of W (sigma^2, or sigma
+    when root), NOT of the Laplacian; ``vectors`` is n x K = U sqrt(n)."""
+    values: np.ndarray
+    vectors: np.ndarray
+
+
+def _csr(n, s, r, p, j, x):
+    import scipy.sparse as sp
+    return sp.csr_matrix((x, j, p), shape=(n, s))
+
+
+def _csr_parts(Z, what="Z"):
+    import scipy.sparse as sp
+    Z = sp.csr_matrix(Z)
+    n, s = Z.shape
+    nnz_row = np.diff(Z.indptr)
+    if n == 0 or not np.all(nnz_row == nnz_row[0]):
+        raise ValueError(f"{what} must store the same number of entries in every row (k-NN sparsity)")
+    Z.sort_indices()
+    r = int(nnz_row[0])
+    return n, s, r, np.ascontiguousarray(Z.indices, dtype=np.int32), np.ascontiguousarray(Z.data, dtype=np.float64)
+
+
+def KNN_cpp(X, U, r=3, distance="Euclidean", output=False, batch=100):
+    """KNN_cpp (src/Utils.cpp:102-192, src/Utils.h:60-62).  Returns ``{"ind_knn": n x r int32
+    (0-based)}`` plus ``"distances_sp"`` (CSR n x s) when ``output``.  ``batch`` is accepted
+    and ignored: it has no numerical effect in the reference either."""
+    del batch
+    X = _f64(X, "X"); U = _f64(U, "U")
+    n, d = X.shape; s = U.shape[0]
+    if U.shape[1] != d:
+        raise ValueError("X and U must have the same number of columns")
+    ind = np.zeros((n, r), dtype=np.int32, order="F")
+    dist = np.zeros((n, r), dtype=np.float64, order="F") if output else None
+    check(_lib.lib().flgp_knn(_ptr(X), n, d, _ptr(U), s, int(r), _b(distance), _ptr(ind), _ptr(dist)))
+    res = {"ind_knn": ind}
+    if output:
+        import scipy.sparse as sp
+        order = np.argsort(ind, axis=1, kind="stable")
+        j = np.take_along_axis(ind, order, axis=1)
+        x = np.take_along_axis(dist, order, axis=1)
+        res["distances_sp"] = sp.csr_matrix((x.ravel(), j.ravel(), np.arange(0, n * r + 1, r)), shape=(n, s))
+    return res
+
+
+def v_to_z_cpp(v):
+    """v_to_z_cpp (src/lae.cpp:137-153)."""
+    v = np.ascontiguousarray(v, dtype=np.float64).ravel()
+    z = np.zeros_like(v)
+    check(_lib.lib().flgp_v_to_z(_ptr(v), v.size, _ptr(z)))
+    return z.reshape(1, -1)
+
+
+def local_anchor_embedding_cpp(x, U):
+    """local_anchor_embedding_cpp (src/lae.cpp:76-133): x length d, U r x d -> 1 x r."""
+    x = np.ascontiguousarray(x, dtype=np.float64).ravel()
+    U = _f64(U, "U")
+    r, d = U.shape
+    if x.size != d:
+        raise ValueError("x and U must have the same dimension")
+    z = np.zeros(r)
+    check(_lib.lib().flgp_local_anchor_embedding(_ptr(x), d, _ptr(U), r, _ptr(z)))
+    return z.reshape(1, -1)
+
+
+def _similarity_call(fn, X, U, r, *extra):
+    X = _f64(X, "X"); U = _f64(U, "U")
+    n, d = X.shape; s = U.shape[0]
+    p = np.zeros(n + 1, dtype=np.int32)
+    j = np.zeros(n * r, dtype=np.int32)
+    x = np.zeros(n * r, dtype=np.float64)
+    return X, U, n, d, s, p, j, x
+
+
+def LAE_cpp(X, U, r=3):
+    """LAE_cpp (src/lae.cpp:48-70) -> CSR n x s with exactly r stored entries per row."""
+    X = _f64(X, "X"); U = _f64(U, "U")
+    n, d = X.shape; s = U.shape[0]
+    if U.shape[1] != d:
+        raise ValueError("X and U must have the same number of columns")
+    p = np.zeros(n + 1, dtype=np.int32); j = np.zeros(n * r, dtype=np.int32); x = np.zeros(n * r)
+    check(_lib.lib().flgp_lae(_ptr(X), n, d, _ptr(U), s, int(r), _ptr(p), _ptr(j), _ptr(x)))
+    return _csr(n, s, r, p, j, x)
+
+
+def cross_similarity_lae_cpp(X, U, r=3, gl="rw"):
+    """cross_similarity_lae_cpp (src/Spectrum.cpp:101-117, defaults src/Spectrum.h:88-92)."""
+    X = _f64(X, "X"); U = _f64(U, "U")
+    n, d = X.shape; s, ucols = U.shape
+    p = np.zeros(n + 1, dtype=np.int32); j = np.zeros(n * r, dtype=np.int32); x = np.zeros(n * r)
+    check(_lib.lib().flgp_cross_similarity_lae(_ptr(X), n, d, _ptr(U), s, ucols, int(r), _b(gl), _ptr(p), _ptr(j), _ptr(x)))
+    return _csr(n, s, r, p, j, x)
+
+
+def cross_similarity_se_cpp(X, U, r, gl, epsilon):
+    """cross_similarity_se_cpp (src/Spectrum.cpp:120-142)."""
+    X = _f64(X, "X"); U = _f64(U, "U")
+    n, d = X.shape; s, ucols = U.shape
+    p = np.zeros(n + 1, dtype=np.int32); j = np.zeros(n * r, dtype=np.int32); x = np.zeros(n * r)
+    check(_lib.lib().flgp_cross_similarity_se(_ptr(X), n, d, _ptr(U), s, ucols, int(r), _b(gl), float(epsilon),
+                                              _ptr(p), _ptr(j), _ptr(x)))
+    return _csr(n, s, r, p, j, x)
+
+
+def graphLaplacian_cpp(Z, gl, num_class=None):
+    """graphLaplacian_cpp (src/Utils.cpp:195-212).  The reference normalises Z in place; this
+    returns the normalised copy."""
+    n, s, r, j, x = _csr_parts(Z)
+    x = x.copy()
+    nc = None if num_class is None else np.ascontiguousarray(num_class, dtype=np.float64)
+    check(_lib.lib().flgp_graph_laplacian(_ptr(j), _ptr(x), n, s, r, _b(gl), _ptr(nc)))
+    return _csr(n, s, r, np.arange(0, n * r + 1, r, dtype=np.int32), j, x)
+
+
+def spectrum_from_Z_cpp(Z, K, root=False):
+    """spectrum_from_Z_cpp (src/Spectrum.cpp:146-161) incl. truncated_SVD_cpp (src/TruncatedSVD.cpp:9-34)."""
+    n, s, r, j, x = _csr_parts(Z)
+    Kk = s if K < 0 else int(K)
+    values = np.zeros(Kk); vectors = np.zeros((n, Kk), order="F")
+    check(_lib.lib().flgp_spectrum_from_Z(_ptr(j), _ptr(x), n, s, r, int(K), int(bool(root)), _ptr(values), _ptr(vectors)))
+    return EigenPair(values, vectors)
+
+
+def truncated_SVD_cpp(Z, K=-1):
+    """truncated_SVD_cpp (src/TruncatedSVD.cpp:9-34) on a matrix that is already scaled:
+    values = sigma^2, vectors = left singular vectors.  Provided through spectrum_from_Z_cpp's
+    device path by undoing its two scalings is not possible, so this mirrors the reference only
+    for matrices whose columns are already unit-scaled; use spectrum_from_Z_cpp."""
+    raise NotImplementedError("use spectrum_from_Z_cpp: the column scaling is fused into the device path")
+
+
+def HK_from_spectrum_cpp(eigenpair, K, t, idx0, idx1):
+    """HK_from_spectrum_cpp (src/Spectrum.cpp:83-94); idx0 / idx1 are 0-based row indices."""
+    vec = _f64(eigenpair.vectors, "vectors")
+    vals = np.ascontiguousarray(eigenpair.values, dtype=np.float64)
+    n = vec.shape[0]
+    if K > vec.shape[1] or K > vals.size:
+        raise ValueError("K exceeds the number of stored eigenpairs")
+    idx0 = np.ascontiguousarray(idx0, dtype=np.int32); idx1 = np.ascontiguousarray(idx1, dtype=np.int32)
+    H = np.zeros((idx0.size, idx1.size), order="F")
+    check(_lib.lib().flgp_hk_from_spectrum(_ptr(vals), _ptr(vec), n, int(K), float(t), _ptr(idx0), idx0.size,
+                                           _ptr(idx1), idx1.size, _ptr(H)))
+    return H
+
+
+def subsample_cpp(X, s, method="kmeans", nstart=1, rng=None):
+    """subsample_cpp (src/Utils.cpp:32-68).  Only ``method="random"`` exists outside R (rows drawn
+    without replacement by a numpy Generator instead of R's ``sample``); k-means anchors come
+    from R (or any other k-means) and are passed to this package as ``U``."""
+    del nstart
+    X = _f64(X, "X")
+    if method == "random":
+        rng = np.random.default_rng(0) if rng is None else rng
+        rows = rng.choice(X.shape[0], size=int(s), replace=False)
+        return np.asfortranarray(X[rows, :])
+    if method in ("kmeans", "minibatchkmeans"):
+        raise NotImplementedError(
+            f"subsample=\"{method}\" is R's stats::kmeans / ClusterR (outside the accelerated path): "
+            "compute the anchors there and pass them as U (s x (d+1), cluster sizes last)")
+    raise FlgpError(-3, "The subsample method is not supported!")
+
+
+def _anchors(X_all, s, models, U, nstart):
+    if U is not None:
+        U = _f64(U, "U")
+        if U.shape[0] != s:
+            raise ValueError(f"U has {U.shape[0]} rows but s = {s}")
+        return U
+    return subsample_cpp(X_all, s, models.get("subsample", "kmeans"), nstart)
+
+
+def heat_kernel_spectrum_cpp(X, X_new, s, r, K=-1, models=None, nstart=1, epsilon=0.1, U=None):
+    """heat_kernel_spectrum_cpp (src/Spectrum.cpp:48-76; defaults src/Spectrum.h:53-59)."""
+    models = dict(_DEFAULT_MODELS_CPP, **(models or {}))
+    X = _f64(X, "X"); X_new = _f64(X_new, "X_new")
+    X_all = np.asfortranarray(np.vstack([X, X_new]))
+    n, d = X_all.shape
+    U = _anchors(X_all, s, models, U, nstart)
+    Kk = s if K < 0 else int(K)
+    values = np.zeros(Kk); vectors = np.zeros((n, Kk), order="F")
+    check(_lib.lib().flgp_heat_kernel_spectrum(_ptr(X_all), n, d, _ptr(U), s, U.shape[1], int(r), int(K),
+                                               _b(models["kernel"]), _b(models["gl"]), int(bool(models["root"])),
+                                               float(epsilon), _ptr(values), _ptr(vectors)))
+    return EigenPair(values, vectors)
+
+
+def heat_kernel_covariance_cpp(X, X_new, s, r, t, K, models, nstart, epsilon, U=None):
+    """heat_kernel_covariance_cpp (src/Spectrum.cpp:28-43): H is (m + m_new) x m."""
+    models = dict(_DEFAULT_MODELS_CPP, **(models or {}))
+    X = _f64(X, "X"); X_new = _f64(X_new, "X_new")
+    m = X.shape[0]
+    X_all = np.asfortranarray(np.vstack([X, X_new]))
+    n, d = X_all.shape
+    U = _anchors(X_all, s, models, U, nstart)
+    H = np.zeros((n, m), order="F")
+    check(_lib.lib().flgp_heat_kernel_covariance(_ptr(X_all), n, m, d, _ptr(U), s, U.shape[1], int(r), float(t), int(K),
+                                                 _b(models["kernel"]), _b(models["gl"]), int(bool(models["root"])),
+                                                 float(epsilon), _ptr(H)))
+    return H
+
+
+def heat_kernel_covariance_rcpp(X, X_new, s, r, t, K=-1, models=None, epsilon=0.1, nstart=1, U=None):
+    """heat_kernel_covariance_rcpp (R/Fit.R:760-770), with the R wrapper's defaults
+    (gl="cluster-normalized", root=TRUE, K=-1)."""
+    models = dict(_DEFAULT_MODELS_R, **(models or {}))
+    return heat_kernel_covariance_cpp(X, X_new, s, r, t, K, models, nstart, epsilon, U=U)
+
+
+def lae_eigenmap(X, s, r=3, ndim=2, subsample="kmeans", norm="cluster-normalized", nstart=1, U=None):
+    """lae_eigenmap (src/Spectrum.cpp:17-25, defaults src/Spectrum.h:43-44)."""
+    X = _f64(X, "X")
+    n, d = X.shape
+    U = _anchors(X, s, dict(subsample=subsample), U, nstart)
+    ev = np.zeros(int(ndim)); vec = np.zeros((n, int(ndim)), order="F")
+    check(_lib.lib().flgp_lae_eigenmap(_ptr(X), n, d, _ptr(U), s, U.shape[1], int(r), int(ndim), _b(norm), _ptr(ev), _ptr(vec)))
+    return {"eigenvalues": ev, "eigenvectors": vec}

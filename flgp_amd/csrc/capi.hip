@@ -1,0 +1,386 @@
+// Host-pointer entry points of libflgp_hip.so: the .Call boundary (include/flgp_hip.h).
+// Each one stages R-owned host buffers into HBM, runs the device stages on one stream and
+// copies the result back; no state survives the call (as the reference: no handles/caches).
+#include "common.h"
+#include <cmath>
+#include <vector>
+
+using namespace flgp;
+
+extern "C" int flgp_dev_anchor_rows(int s);
+extern "C" int flgp_dev_v_to_z(void *stream, const double *d_v, int r, double *d_z);
+extern "C" size_t flgp_dev_hk_workspace(int n0, int n1, int K, int gather0);
+
+namespace {
+
+struct Stream {
+  hipStream_t s = nullptr;
+  ~Stream() { if (s) (void)hipStreamDestroy(s); }
+  int create() { FLGP_HIP(hipStreamCreate(&s)); return FLGP_OK; }
+};
+
+int check_distance(const char *distance) {
+  if (distance && !strcmp(distance, "Euclidean")) return FLGP_OK;
+  // reference: Rcpp::stop("The distance method of KNN is not supported!\n"), src/Utils.cpp:123
+  set_error("The distance method of KNN is not supported!");
+  return FLGP_ERR_UNSUPPORTED;
+}
+
+int h2d(void *dst, const void *src, size_t bytes, hipStream_t st) {
+  if (bytes) FLGP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
+  return FLGP_OK;
+}
+int d2h(void *dst, const void *src, size_t bytes, hipStream_t st) {
+  if (bytes) FLGP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, st));
+  return FLGP_OK;
+}
+
+// device-side state of one similarity matrix: anchors, k-NN, ELL (+ CSC view)
+struct Sim {
+  DevBuf X, U, Ut, uu, knn_idx, knn_dist, ell_idx, ell_val, colptr, pos, colsum, work, num_class;
+  int n = 0, d = 0, s = 0, r = 0;
+  bool have_csc = false;
+};
+
+int upload_points(Sim &S, hipStream_t st, const double *X, int n, int d, const double *U, int s, int ucols,
+                  bool need_sizes) {
+  FLGP_REQUIRE(X && U, "null pointer");
+  FLGP_REQUIRE(n >= 1 && d >= 1 && s >= 1, "bad shape n=%d d=%d s=%d", n, d, s);
+  FLGP_REQUIRE(ucols == d || ucols == d + 1, "U must have d or d+1 columns (d=%d, got %d)", d, ucols);
+  FLGP_REQUIRE(!need_sizes || ucols == d + 1,
+               "gl=\"cluster-normalized\" needs the cluster sizes in column d+1 of U (the reference reads out of bounds here)");
+  const int dpad = flgp_dev_anchor_dpad(d);
+  FLGP_REQUIRE(dpad > 0, "kernels are built for 1 <= d <= %d (got %d)", FLGP_DMAX, d);
+  S.n = n; S.d = d; S.s = s;
+  const int rows = flgp_dev_anchor_rows(s);
+  FLGP_TRY(S.X.alloc(sizeof(double) * (size_t)n * d));
+  FLGP_TRY(S.U.alloc(sizeof(double) * (size_t)s * ucols));
+  FLGP_TRY(S.Ut.alloc(sizeof(double) * (size_t)rows * dpad));
+  FLGP_TRY(S.uu.alloc(sizeof(double) * (size_t)rows));
+  FLGP_TRY(h2d(S.X.p, X, sizeof(double) * (size_t)n * d, st));
+  FLGP_TRY(h2d(S.U.p, U, sizeof(double) * (size_t)s * ucols, st));
+  return flgp_dev_anchor_prep(st, S.U.as<double>(), s, s, d, S.Ut.as<double>(), S.uu.as<double>());
+}
+
+int run_knn(Sim &S, hipStream_t st, int r, bool want_dist) {
+  FLGP_REQUIRE(r >= 1 && r <= S.s, "need 1 <= r <= s (r=%d, s=%d)", r, S.s);
+  S.r = r;
+  FLGP_TRY(S.knn_idx.alloc(sizeof(int) * (size_t)S.n * r));
+  if (want_dist) FLGP_TRY(S.knn_dist.alloc(sizeof(double) * (size_t)S.n * r));
+  return flgp_dev_knn(st, S.X.as<double>(), S.n, S.n, S.d, S.Ut.as<double>(), S.uu.as<double>(), S.s, r,
+                      S.knn_idx.as<int>(), want_dist ? S.knn_dist.as<double>() : nullptr, S.n);
+}
+
+int alloc_ell(Sim &S) {
+  FLGP_TRY(S.ell_idx.alloc(sizeof(int) * (size_t)S.n * S.r));
+  return S.ell_val.alloc(sizeof(double) * (size_t)S.n * S.r);
+}
+
+int build_csc(Sim &S, hipStream_t st) {
+  if (S.have_csc) return FLGP_OK;
+  const size_t wb = flgp_dev_csc_workspace(S.n, S.s, S.r);
+  FLGP_TRY(S.work.alloc(wb));
+  FLGP_TRY(S.colptr.alloc(sizeof(int) * (size_t)(S.s + 1)));
+  FLGP_TRY(S.pos.alloc(sizeof(int) * (size_t)S.n * S.r));
+  FLGP_TRY(S.colsum.alloc(sizeof(double) * (size_t)S.s));
+  FLGP_TRY(flgp_dev_csc_build(st, S.ell_idx.as<int>(), S.n, S.s, S.r, S.colptr.as<int>(), S.pos.as<int>(), S.work.p, wb));
+  S.have_csc = true;
+  return FLGP_OK;
+}
+
+// graphLaplacian_cpp on the device ELL (reference src/Utils.cpp:195-212)
+int laplacian(Sim &S, hipStream_t st, int gl, const double *d_num_class) {
+  if (gl != FLGP_GL_RW) {
+    FLGP_TRY(build_csc(S, st));
+    FLGP_TRY(flgp_dev_colsum(st, S.ell_val.as<double>(), S.colptr.as<int>(), S.pos.as<int>(), S.s, S.colsum.as<double>()));
+    FLGP_TRY(flgp_dev_col_scale(st, S.ell_idx.as<int>(), S.ell_val.as<double>(), S.n, S.r, S.colsum.as<double>(),
+                                gl == FLGP_GL_CLUSTER_NORMALIZED ? d_num_class : nullptr, 0));
+  }
+  return flgp_dev_row_normalize(st, S.ell_val.as<double>(), S.n, S.r);
+}
+
+// cross_similarity_{lae,se}_cpp after the points are on the device (reference src/Spectrum.cpp:101-142)
+int cross_similarity(Sim &S, hipStream_t st, int r, int kernel_se, int gl, double epsilon, int ucols) {
+  FLGP_TRY(run_knn(S, st, r, kernel_se != 0));
+  FLGP_TRY(alloc_ell(S));
+  if (kernel_se)
+    FLGP_TRY(flgp_dev_se_weights(st, S.knn_idx.as<int>(), S.knn_dist.as<double>(), S.n, S.n, r, epsilon,
+                                 S.ell_idx.as<int>(), S.ell_val.as<double>()));
+  else
+    FLGP_TRY(flgp_dev_lae(st, S.X.as<double>(), S.n, S.n, S.d, S.Ut.as<double>(), S.s, r, S.knn_idx.as<int>(), S.n,
+                          S.ell_idx.as<int>(), S.ell_val.as<double>()));
+  if (gl < 0) return FLGP_OK;  // LAE_cpp alone: no graph-Laplacian normalisation
+  const double *sizes = (ucols == S.d + 1) ? S.U.as<double>() + (size_t)S.d * S.s : nullptr;  // U.col(d)
+  return laplacian(S, st, gl, sizes);
+}
+
+int csr_out(Sim &S, hipStream_t st, int *csr_p, int *csr_j, double *csr_x) {
+  FLGP_TRY(d2h(csr_j, S.ell_idx.p, sizeof(int) * (size_t)S.n * S.r, st));
+  FLGP_TRY(d2h(csr_x, S.ell_val.p, sizeof(double) * (size_t)S.n * S.r, st));
+  FLGP_HIP(hipStreamSynchronize(st));
+  if (csr_p)
+    for (long i = 0; i <= S.n; ++i) csr_p[i] = (int)(i * S.r);
+  return FLGP_OK;
+}
+
+// spectrum_from_Z_cpp on the device ELL (reference src/Spectrum.cpp:146-161): leaves values (K)
+// and vectors (n x K) on the device
+struct Spectrum {
+  DevBuf G, eig, V, values, vectors, work;
+  int K = 0;
+};
+
+int spectrum(Sim &S, hipStream_t st, int K, int root, Spectrum &P, int *info) {
+  if (K < 0) K = S.s;   // reference: K < 0 -> s (src/Spectrum.cpp:31-33,69-71; src/TruncatedSVD.cpp:11-13)
+  FLGP_REQUIRE(K >= 1 && K <= S.s, "need 1 <= K <= s (K=%d, s=%d)", K, S.s);
+  P.K = K;
+  FLGP_TRY(build_csc(S, st));
+  // A = Z diag(1/sqrt(|colsum|+1e-9))  (:149-150)
+  FLGP_TRY(flgp_dev_colsum(st, S.ell_val.as<double>(), S.colptr.as<int>(), S.pos.as<int>(), S.s, S.colsum.as<double>()));
+  FLGP_TRY(flgp_dev_col_scale(st, S.ell_idx.as<int>(), S.ell_val.as<double>(), S.n, S.r, S.colsum.as<double>(), nullptr, 1));
+  // Gram + top-K eigenpairs (replaces RSpectra::svds / BDCSVD, src/TruncatedSVD.cpp:17-30)
+  FLGP_TRY(P.G.alloc(sizeof(double) * (size_t)S.s * S.s));
+  FLGP_TRY(flgp_dev_gram(st, S.ell_idx.as<int>(), S.ell_val.as<double>(), S.n, S.s, S.r, S.colptr.as<int>(),
+                         S.pos.as<int>(), P.G.as<double>(), S.s));
+  const size_t wb = flgp_dev_eig_workspace(S.s, K);
+  FLGP_TRY(P.work.alloc(wb));
+  FLGP_TRY(P.eig.alloc(sizeof(double) * (size_t)K));
+  FLGP_TRY(P.V.alloc(sizeof(double) * (size_t)S.s * K));
+  FLGP_TRY(flgp_dev_eig_topk(st, P.G.as<double>(), S.s, S.s, K, 0.0, P.eig.as<double>(), P.V.as<double>(), S.s,
+                             P.work.p, wb, info));
+  // u = A v / sigma, vectors = u sqrt(n), values = sigma^2 (or sigma if root)  (:153-158)
+  FLGP_TRY(P.values.alloc(sizeof(double) * (size_t)K));
+  FLGP_TRY(P.vectors.alloc(sizeof(double) * (size_t)S.n * K));
+  return flgp_dev_u_recover(st, S.ell_idx.as<int>(), S.ell_val.as<double>(), S.n, S.r, P.V.as<double>(), S.s, S.s,
+                            P.eig.as<double>(), K, std::sqrt((double)S.n), root, P.vectors.as<double>(), S.n,
+                            P.values.as<double>());
+}
+
+int parse_kernel(const char *kernel, int *se) {
+  if (kernel && !strcmp(kernel, "lae")) { *se = 0; return FLGP_OK; }
+  if (kernel && !strcmp(kernel, "se")) { *se = 1; return FLGP_OK; }
+  // the reference only prints and carries on with an empty Z (src/Spectrum.cpp:65-67); here it is an error
+  set_error("The kernel type is not supported!");
+  return FLGP_ERR_UNSUPPORTED;
+}
+
+bool is_range(const int *idx, int cnt) {
+  for (int i = 1; i < cnt; ++i)
+    if (idx[i] != idx[0] + i) return false;
+  return true;
+}
+
+}  // namespace
+
+extern "C" int flgp_knn(const double *X, int n, int d, const double *U, int s, int r, const char *distance,
+                        int *ind_knn, double *dist) {
+  FLGP_TRY(check_distance(distance));
+  FLGP_REQUIRE(ind_knn, "KNN: null pointer");
+  if (n == 0) return FLGP_OK;
+  Stream st;
+  FLGP_TRY(st.create());
+  Sim S;
+  FLGP_TRY(upload_points(S, st.s, X, n, d, U, s, d, false));
+  FLGP_TRY(run_knn(S, st.s, r, dist != nullptr));
+  FLGP_TRY(d2h(ind_knn, S.knn_idx.p, sizeof(int) * (size_t)n * r, st.s));
+  if (dist) FLGP_TRY(d2h(dist, S.knn_dist.p, sizeof(double) * (size_t)n * r, st.s));
+  FLGP_HIP(hipStreamSynchronize(st.s));
+  return FLGP_OK;
+}
+
+extern "C" int flgp_v_to_z(const double *v, int r, double *z) {
+  FLGP_REQUIRE(v && z, "v_to_z: null pointer");
+  FLGP_REQUIRE(r >= 1 && r <= FLGP_RMAX, "v_to_z: need 1 <= r <= %d (got %d)", FLGP_RMAX, r);
+  Stream st;
+  FLGP_TRY(st.create());
+  DevBuf dv, dz;
+  FLGP_TRY(dv.alloc(sizeof(double) * r));
+  FLGP_TRY(dz.alloc(sizeof(double) * r));
+  FLGP_TRY(h2d(dv.p, v, sizeof(double) * r, st.s));
+  FLGP_TRY(flgp_dev_v_to_z(st.s, dv.as<double>(), r, dz.as<double>()));
+  FLGP_TRY(d2h(z, dz.p, sizeof(double) * r, st.s));
+  FLGP_HIP(hipStreamSynchronize(st.s));
+  return FLGP_OK;
+}
+
+extern "C" int flgp_local_anchor_embedding(const double *x, int d, const double *U, int r, double *z) {
+  FLGP_REQUIRE(x && U && z, "local_anchor_embedding: null pointer");
+  FLGP_REQUIRE(r >= 1 && r <= FLGP_RMAX, "local_anchor_embedding: need 1 <= r <= %d (got %d)", FLGP_RMAX, r);
+  Stream st;
+  FLGP_TRY(st.create());
+  Sim S;
+  // one point, its r anchors in the given order: "k-NN" indices are 0..r-1
+  FLGP_TRY(upload_points(S, st.s, x, 1, d, U, r, d, false));
+  S.r = r;
+  std::vector<int> ids(r);
+  for (int a = 0; a < r; ++a) ids[a] = a;
+  FLGP_TRY(S.knn_idx.alloc(sizeof(int) * r));
+  FLGP_TRY(h2d(S.knn_idx.p, ids.data(), sizeof(int) * r, st.s));
+  FLGP_TRY(alloc_ell(S));
+  FLGP_TRY(flgp_dev_lae(st.s, S.X.as<double>(), 1, 1, d, S.Ut.as<double>(), r, r, S.knn_idx.as<int>(), 1,
+                        S.ell_idx.as<int>(), S.ell_val.as<double>()));
+  FLGP_TRY(d2h(z, S.ell_val.p, sizeof(double) * r, st.s));  // sorted by anchor index == input order
+  FLGP_HIP(hipStreamSynchronize(st.s));
+  return FLGP_OK;
+}
+
+extern "C" int flgp_lae(const double *X, int n, int d, const double *U, int s, int r, int *csr_p, int *csr_j,
+                        double *csr_x) {
+  FLGP_REQUIRE(csr_j && csr_x, "LAE: null pointer");
+  Stream st;
+  FLGP_TRY(st.create());
+  Sim S;
+  FLGP_TRY(upload_points(S, st.s, X, n, d, U, s, d, false));
+  FLGP_TRY(cross_similarity(S, st.s, r, 0, -1 /* no Laplacian */, 0.0, d));
+  return csr_out(S, st.s, csr_p, csr_j, csr_x);
+}
+
+extern "C" int flgp_cross_similarity_lae(const double *X, int n, int d, const double *U, int s, int ucols, int r,
+                                         const char *gl, int *csr_p, int *csr_j, double *csr_x) {
+  const int glc = flgp_parse_gl(gl);
+  if (glc < 0) return glc;
+  FLGP_REQUIRE(csr_j && csr_x, "cross_similarity_lae: null pointer");
+  Stream st;
+  FLGP_TRY(st.create());
+  Sim S;
+  FLGP_TRY(upload_points(S, st.s, X, n, d, U, s, ucols, glc == FLGP_GL_CLUSTER_NORMALIZED));
+  FLGP_TRY(cross_similarity(S, st.s, r, 0, glc, 0.0, ucols));
+  return csr_out(S, st.s, csr_p, csr_j, csr_x);
+}
+
+extern "C" int flgp_cross_similarity_se(const double *X, int n, int d, const double *U, int s, int ucols, int r,
+                                        const char *gl, double epsilon, int *csr_p, int *csr_j, double *csr_x) {
+  const int glc = flgp_parse_gl(gl);
+  if (glc < 0) return glc;
+  FLGP_REQUIRE(csr_j && csr_x, "cross_similarity_se: null pointer");
+  Stream st;
+  FLGP_TRY(st.create());
+  Sim S;
+  FLGP_TRY(upload_points(S, st.s, X, n, d, U, s, ucols, glc == FLGP_GL_CLUSTER_NORMALIZED));
+  FLGP_TRY(cross_similarity(S, st.s, r, 1, glc, epsilon, ucols));
+  return csr_out(S, st.s, csr_p, csr_j, csr_x);
+}
+
+extern "C" int flgp_graph_laplacian(const int *csr_j, double *csr_x, int n, int s, int r, const char *gl,
+                                    const double *num_class) {
+  const int glc = flgp_parse_gl(gl);
+  if (glc < 0) return glc;
+  FLGP_REQUIRE(csr_j && csr_x && n >= 1 && s >= 1 && r >= 1, "graph_laplacian: bad arguments");
+  FLGP_REQUIRE(glc != FLGP_GL_CLUSTER_NORMALIZED || num_class, "graph_laplacian: cluster-normalized needs num_class");
+  Stream st;
+  FLGP_TRY(st.create());
+  Sim S;
+  S.n = n; S.s = s; S.r = r;
+  FLGP_TRY(alloc_ell(S));
+  FLGP_TRY(h2d(S.ell_idx.p, csr_j, sizeof(int) * (size_t)n * r, st.s));
+  FLGP_TRY(h2d(S.ell_val.p, csr_x, sizeof(double) * (size_t)n * r, st.s));
+  if (num_class) {
+    FLGP_TRY(S.num_class.alloc(sizeof(double) * (size_t)s));
+    FLGP_TRY(h2d(S.num_class.p, num_class, sizeof(double) * (size_t)s, st.s));
+  }
+  FLGP_TRY(laplacian(S, st.s, glc, num_class ? S.num_class.as<double>() : nullptr));
+  FLGP_TRY(d2h(csr_x, S.ell_val.p, sizeof(double) * (size_t)n * r, st.s));
+  FLGP_HIP(hipStreamSynchronize(st.s));
+  return FLGP_OK;
+}
+
+extern "C" int flgp_spectrum_from_Z(const int *csr_j, const double *csr_x, int n, int s, int r, int K, int root,
+                                    double *values, double *vectors) {
+  FLGP_REQUIRE(csr_j && csr_x && values && vectors && n >= 1 && s >= 1 && r >= 1, "spectrum_from_Z: bad arguments");
+  Stream st;
+  FLGP_TRY(st.create());
+  Sim S;
+  S.n = n; S.s = s; S.r = r;
+  FLGP_TRY(alloc_ell(S));
+  FLGP_TRY(h2d(S.ell_idx.p, csr_j, sizeof(int) * (size_t)n * r, st.s));
+  FLGP_TRY(h2d(S.ell_val.p, csr_x, sizeof(double) * (size_t)n * r, st.s));
+  Spectrum P;
+  FLGP_TRY(spectrum(S, st.s, K, root, P, nullptr));
+  FLGP_TRY(d2h(values, P.values.p, sizeof(double) * (size_t)P.K, st.s));
+  FLGP_TRY(d2h(vectors, P.vectors.p, sizeof(double) * (size_t)n * P.K, st.s));
+  FLGP_HIP(hipStreamSynchronize(st.s));
+  return FLGP_OK;
+}
+
+extern "C" int flgp_hk_from_spectrum(const double *values, const double *vectors, int n, int K, double t,
+                                     const int *idx0, int n0, const int *idx1, int n1, double *H) {
+  FLGP_REQUIRE(values && vectors && idx0 && idx1 && H, "HK_from_spectrum: null pointer");
+  FLGP_REQUIRE(n >= 1 && K >= 1 && n0 >= 0 && n1 >= 0, "HK_from_spectrum: bad shape");
+  for (int a = 0; a < n0; ++a) FLGP_REQUIRE(idx0[a] >= 0 && idx0[a] < n, "HK_from_spectrum: idx0[%d]=%d out of range", a, idx0[a]);
+  for (int b = 0; b < n1; ++b) FLGP_REQUIRE(idx1[b] >= 0 && idx1[b] < n, "HK_from_spectrum: idx1[%d]=%d out of range", b, idx1[b]);
+  if (n0 == 0 || n1 == 0) return FLGP_OK;
+  Stream st;
+  FLGP_TRY(st.create());
+  DevBuf dval, dvec, di0, di1, dH, work;
+  const bool r0 = is_range(idx0, n0), r1 = is_range(idx1, n1);
+  FLGP_TRY(dval.alloc(sizeof(double) * K));
+  FLGP_TRY(dvec.alloc(sizeof(double) * (size_t)n * K));
+  FLGP_TRY(dH.alloc(sizeof(double) * (size_t)n0 * n1));
+  FLGP_TRY(work.alloc(flgp_dev_hk_workspace(n0, n1, K, !r0)));
+  FLGP_TRY(h2d(dval.p, values, sizeof(double) * K, st.s));
+  FLGP_TRY(h2d(dvec.p, vectors, sizeof(double) * (size_t)n * K, st.s));
+  if (!r0) { FLGP_TRY(di0.alloc(sizeof(int) * n0)); FLGP_TRY(h2d(di0.p, idx0, sizeof(int) * n0, st.s)); }
+  if (!r1) { FLGP_TRY(di1.alloc(sizeof(int) * n1)); FLGP_TRY(h2d(di1.p, idx1, sizeof(int) * n1, st.s)); }
+  FLGP_TRY(flgp_dev_hk(st.s, dval.as<double>(), K, t, dvec.as<double>(), n, r0 ? nullptr : di0.as<int>(), r0 ? idx0[0] : 0,
+                       n0, dvec.as<double>(), n, r1 ? nullptr : di1.as<int>(), r1 ? idx1[0] : 0, n1, dH.as<double>(), n0,
+                       work.as<double>()));
+  FLGP_TRY(d2h(H, dH.p, sizeof(double) * (size_t)n0 * n1, st.s));
+  FLGP_HIP(hipStreamSynchronize(st.s));
+  return FLGP_OK;
+}
+
+extern "C" int flgp_heat_kernel_spectrum(const double *X_all, int n, int d, const double *U, int s, int ucols,
+                                         int r, int K, const char *kernel, const char *gl, int root,
+                                         double epsilon, double *values, double *vectors) {
+  int se = 0;
+  FLGP_TRY(parse_kernel(kernel, &se));
+  const int glc = flgp_parse_gl(gl);
+  if (glc < 0) return glc;
+  FLGP_REQUIRE(values && vectors, "heat_kernel_spectrum: null pointer");
+  Stream st;
+  FLGP_TRY(st.create());
+  Sim S;
+  FLGP_TRY(upload_points(S, st.s, X_all, n, d, U, s, ucols, glc == FLGP_GL_CLUSTER_NORMALIZED));
+  FLGP_TRY(cross_similarity(S, st.s, r, se, glc, epsilon, ucols));
+  Spectrum P;
+  FLGP_TRY(spectrum(S, st.s, K, root, P, nullptr));
+  FLGP_TRY(d2h(values, P.values.p, sizeof(double) * (size_t)P.K, st.s));
+  FLGP_TRY(d2h(vectors, P.vectors.p, sizeof(double) * (size_t)n * P.K, st.s));
+  FLGP_HIP(hipStreamSynchronize(st.s));
+  return FLGP_OK;
+}
+
+extern "C" int flgp_heat_kernel_covariance(const double *X_all, int n, int m, int d, const double *U, int s,
+                                           int ucols, int r, double t, int K, const char *kernel, const char *gl,
+                                           int root, double epsilon, double *H) {
+  int se = 0;
+  FLGP_TRY(parse_kernel(kernel, &se));
+  const int glc = flgp_parse_gl(gl);
+  if (glc < 0) return glc;
+  FLGP_REQUIRE(H && m >= 1 && m <= n, "heat_kernel_covariance: need 1 <= m <= n and H");
+  Stream st;
+  FLGP_TRY(st.create());
+  Sim S;
+  FLGP_TRY(upload_points(S, st.s, X_all, n, d, U, s, ucols, glc == FLGP_GL_CLUSTER_NORMALIZED));
+  FLGP_TRY(cross_similarity(S, st.s, r, se, glc, epsilon, ucols));
+  Spectrum P;
+  FLGP_TRY(spectrum(S, st.s, K, root, P, nullptr));
+  // H = V[0:n] diag(exp(-t(1-values))) V[0:m]^T  (idx0 = 0..n-1, idx1 = 0..m-1, src/Spectrum.cpp:38-40)
+  DevBuf dH, work;
+  FLGP_TRY(dH.alloc(sizeof(double) * (size_t)n * m));
+  FLGP_TRY(work.alloc(flgp_dev_hk_workspace(n, m, P.K, 0)));
+  FLGP_TRY(flgp_dev_hk(st.s, P.values.as<double>(), P.K, t, P.vectors.as<double>(), n, nullptr, 0, n,
+                       P.vectors.as<double>(), n, nullptr, 0, m, dH.as<double>(), n, work.as<double>()));
+  FLGP_TRY(d2h(H, dH.p, sizeof(double) * (size_t)n * m, st.s));
+  FLGP_HIP(hipStreamSynchronize(st.s));
+  return FLGP_OK;
+}
+
+extern "C" int flgp_lae_eigenmap(const double *X, int n, int d, const double *U, int s, int ucols, int r, int ndim,
+                                 const char *norm, double *eigenvalues, double *eigenvectors) {
+  // lae_eigenmap (src/Spectrum.cpp:17-25): spectrum with root = true, eigenvalues = 1 - values
+  FLGP_REQUIRE(eigenvalues && eigenvectors && ndim >= 1, "lae_eigenmap: bad arguments");
+  FLGP_TRY(flgp_heat_kernel_spectrum(X, n, d, U, s, ucols, r, ndim, "lae", norm, 1, 0.0, eigenvalues, eigenvectors));
+  for (int k = 0; k < ndim; ++k) eigenvalues[k] = 1.0 - eigenvalues[k];
+  return FLGP_OK;
+}

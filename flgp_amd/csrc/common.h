@@ -1,0 +1,66 @@
+// Shared host-side helpers for libflgp_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include "../../include/flgp_hip.h"
+
+namespace flgp {
+
+void set_error(const char *fmt, ...);
+int tuning(const char *key, int dflt);
+
+inline int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+  set_error("HIP error %s (%d) in %s at %s:%d", hipGetErrorString(e), (int)e, what, file, line);
+  return FLGP_ERR_HIP;
+}
+
+#define FLGP_HIP(call)                                                         \
+  do {                                                                         \
+    hipError_t e_ = (call);                                                    \
+    if (e_ != hipSuccess) return ::flgp::hip_fail(e_, #call, __FILE__, __LINE__); \
+  } while (0)
+
+#define FLGP_TRY(call)            \
+  do {                            \
+    int rc_ = (call);             \
+    if (rc_ != FLGP_OK) return rc_; \
+  } while (0)
+
+#define FLGP_REQUIRE(cond, ...)      \
+  do {                               \
+    if (!(cond)) {                   \
+      ::flgp::set_error(__VA_ARGS__); \
+      return FLGP_ERR_INVALID;       \
+    }                                \
+  } while (0)
+
+inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+
+// RAII device buffer for the host-pointer entry points
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() { if (p) (void)hipFree(p); }
+  int alloc(size_t bytes) {
+    if (bytes == 0) bytes = 8;
+    hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) { p = nullptr; set_error("hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e)); return FLGP_ERR_NOMEM; }
+    return FLGP_OK;
+  }
+  template <class T> T *as() { return (T *)p; }
+};
+
+inline int check_launch(const char *what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { set_error("launch of %s failed: %s", what, hipGetErrorString(e)); return FLGP_ERR_HIP; }
+  return FLGP_OK;
+}
+
+// C(i,j) = alpha * sum_k A(i,k) B(k,j) + beta * E(i,j) + gamma * E2(i,j)   (gemm.hip)
+int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double *A, long a_is, long a_ks,
+                const double *B, long b_ks, long b_js, double beta, const double *E, long e_is, long e_js,
+                double *C, long c_is, long c_js, double *work, size_t work_elems, double gamma,
+                const double *E2);
+
+}  // namespace flgp

@@ -1,0 +1,538 @@
+// k6 (dense half): top-K eigenpairs of the s x s Gram matrix G = A^T A on the device.
+//
+// Replaces the RSpectra::svds call of truncated_SVD_cpp (reference src/TruncatedSVD.cpp:23-30:
+// Spectra's implicitly restarted Lanczos on the implicit s x s operator, one vector at a time,
+// entered through an R callback) and its K == s Eigen::BDCSVD branch (:17-20).
+//
+// MI355X design: a BLOCK method, so that every pass over G is an fp64 MFMA GEMM instead of a
+// memory-bound mat-vec -- Chebyshev-filtered subspace iteration:
+//     Y  <- p_m(G) Q          m GEMMs (s x s x b) with the three-term recurrence in the epilogue
+//     Q1 <- orth(Y)           S = Y^T Y (split-K GEMM), eigen-decomposition of S (block Jacobi),
+//                             Q1 = Y W L^-1/2  ("SVQB": no Cholesky breakdown on ill-conditioned Y)
+//     Rayleigh-Ritz           Z = G Q1, T = Q1^T Z, T = Yr Th Yr^T (block Jacobi), Q = Q1 Yr, GQ = Z Yr
+//     residuals               |G q_j - th_j q_j| for the K wanted pairs -> host decides to stop
+// p_m damps [0, th_b] (G is PSD) and is scaled to 1 at the top Ritz value; b = K + guard columns.
+// A block of width b >= the multiplicity of lambda = 1 (one per connected component of the
+// anchor graph) resolves repeated eigenvalues, which single-vector Lanczos only finds through
+// round-off.
+//
+// The small dense symmetric eigenproblems (b x b; or s x s itself when K == s / s is small)
+// use a one-sided block Jacobi: block-column pairs are orthogonalised inside LDS by one
+// workgroup each, rounds follow a round-robin tournament, one launch per round (independent
+// pairs in a round; a launch boundary is the inter-workgroup barrier).  Rotations are
+// accumulated in V explicitly, so V stays orthogonal to rounding even for tiny eigenvalues.
+#include "common.h"
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+namespace flgp {
+
+// ------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// deterministic start block: uniform(-1,1) from a counter hash
+__global__ void eig_init_q_kernel(double *__restrict__ Q, int s, int b, int ldq) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)s * b) return;
+  const int i = (int)(e % s), j = (int)(e / s);
+  const unsigned long long h = mix64((unsigned long long)e * 2 + 0x5851F42D4C957F2Dull);
+  Q[(size_t)j * ldq + i] = ((double)(h >> 11) + 0.5) * (2.0 / 9007199254740992.0) - 1.0;
+}
+
+// out = a * X + b * Y (elementwise, s x b, same ld)
+__global__ void eig_axpby_kernel(double a, const double *__restrict__ X, double b, const double *__restrict__ Y,
+                                 double *__restrict__ out, long total) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < total) out[e] = a * X[e] + b * Y[e];
+}
+
+// Jacobi set-up: B = T (symmetrised), V = I
+__global__ void jac_init_kernel(const double *__restrict__ T, int ldt, int b, double *__restrict__ B,
+                                double *__restrict__ V, int ldb, int *__restrict__ flags) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e == 0) { flags[0] = 0; flags[1] = 0; }
+  if (e >= (long)b * b) return;
+  const int i = (int)(e % b), j = (int)(e / b);
+  B[(size_t)j * ldb + i] = 0.5 * (T[(size_t)j * ldt + i] + T[(size_t)i * ldt + j]);
+  V[(size_t)j * ldb + i] = (i == j) ? 1.0 : 0.0;
+}
+
+// round-robin tournament pairing of m2 (even) players, round rr in [0, m2-1), pair k in [0, m2/2)
+__device__ __host__ inline void rr_pair(int m2, int rr, int k, int &p, int &q) {
+  const int m = m2 - 1;
+  if (k == 0) { p = m; q = rr % m; }
+  else { p = (rr + k) % m; q = (rr + m - k) % m; }
+  if (p > q) { const int t = p; p = q; q = t; }
+}
+
+// One workgroup orthogonalises the 2w columns of block columns (I, J) against each other:
+// one cyclic sweep of Hestenes rotations inside LDS, applied to B and accumulated into V.
+// flags[0]: number of rotations applied in this sweep (convergence when it stays 0)
+// flags[1]: "converged" latch set by the host-side protocol (kernel exits early)
+__global__ __launch_bounds__(256) void jac_round_kernel(double *__restrict__ B, double *__restrict__ V, int b,
+                                                        int ldb, int w, int nbc, int round, double tol,
+                                                        int *__restrict__ flags) {
+  extern __shared__ double sm[];
+  if (flags[1]) return;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  int I, J;
+  rr_pair(nbc, round, blockIdx.x, I, J);
+  const int cI = I * w, cJ = J * w;
+  if (cI >= b) return;                      // padding block column
+  const int wI = (b - cI < w) ? b - cI : w;
+  const int wJ = (cJ >= b) ? 0 : ((b - cJ < w) ? b - cJ : w);
+  const int ncol = wI + wJ;                 // live columns
+  const int bp = b + 16;                    // padded column stride in LDS
+  double *LB = sm;                          // [2w][bp]
+  double *LV = sm + (size_t)2 * w * bp;
+  // load
+  for (int c = 0; c < ncol; ++c) {
+    const int gc = (c < wI) ? cI + c : cJ + (c - wI);
+    for (int i = tid; i < b; i += nt) {
+      LB[(size_t)c * bp + i] = B[(size_t)gc * ldb + i];
+      LV[(size_t)c * bp + i] = V[(size_t)gc * ldb + i];
+    }
+  }
+  __syncthreads();
+  if (ncol >= 2) {
+    const int m2 = (ncol + 1) & ~1;         // players (one bye when ncol is odd)
+    const int npair = m2 / 2;
+    // threads per pair: a power of two <= 64 so that the reductions stay inside a wave
+    int gs = 64;
+    while (gs > 1 && gs * npair > nt) gs >>= 1;
+    const int grp = tid / gs, gl = tid % gs;
+    int rotations = 0;
+    for (int rr = 0; rr < m2 - 1; ++rr) {
+      for (int k0 = 0; k0 < npair; k0 += nt / gs) {   // more pairs than groups: several passes
+        const int k = k0 + grp;
+        int p = 0, q = 0;
+        bool act = k < npair;
+        if (act) { rr_pair(m2, rr, k, p, q); act = (q < ncol); }
+        double al = 0.0, be = 0.0, ga = 0.0;
+        if (act) {
+          const double *bp_ = LB + (size_t)p * bp, *bq_ = LB + (size_t)q * bp;
+          for (int i = gl; i < b; i += gs) {
+            const double x = bp_[i], y = bq_[i];
+            al = __builtin_fma(x, x, al); be = __builtin_fma(y, y, be); ga = __builtin_fma(x, y, ga);
+          }
+        }
+        for (int off = gs >> 1; off > 0; off >>= 1) {
+          al += __shfl_xor(al, off, 64); be += __shfl_xor(be, off, 64); ga += __shfl_xor(ga, off, 64);
+        }
+        if (act && __builtin_fabs(ga) > tol * __builtin_sqrt(al * be) && al > 0.0 && be > 0.0) {
+          const double zeta = (be - al) / (2.0 * ga);
+          const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (__builtin_fabs(zeta) + __builtin_sqrt(1.0 + zeta * zeta));
+          const double cs = 1.0 / __builtin_sqrt(1.0 + tt * tt), sn = cs * tt;
+          double *bp_ = LB + (size_t)p * bp, *bq_ = LB + (size_t)q * bp;
+          double *vp_ = LV + (size_t)p * bp, *vq_ = LV + (size_t)q * bp;
+          for (int i = gl; i < b; i += gs) {
+            const double x = bp_[i], y = bq_[i];
+            bp_[i] = cs * x - sn * y; bq_[i] = sn * x + cs * y;
+            const double u = vp_[i], v = vq_[i];
+            vp_[i] = cs * u - sn * v; vq_[i] = sn * u + cs * v;
+          }
+          if (gl == 0) ++rotations;
+        }
+      }
+      __syncthreads();
+    }
+    if (rotations) atomicAdd(&flags[0], rotations);
+  }
+  // store
+  for (int c = 0; c < ncol; ++c) {
+    const int gc = (c < wI) ? cI + c : cJ + (c - wI);
+    for (int i = tid; i < b; i += nt) {
+      B[(size_t)gc * ldb + i] = LB[(size_t)c * bp + i];
+      V[(size_t)gc * ldb + i] = LV[(size_t)c * bp + i];
+    }
+  }
+}
+
+// after a sweep: latch convergence (no rotation applied) and reset the counter
+__global__ void jac_sweep_end_kernel(int *__restrict__ flags) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    if (flags[0] == 0) flags[1] = 1;
+    flags[2] += 1;       // sweeps run (only counts while not converged)
+    flags[0] = 0;
+  }
+}
+
+// eigenvalue j = v_j . (T v_j) = v_j . B_j  (B = T V)
+__global__ void jac_values_kernel(const double *__restrict__ B, const double *__restrict__ V, int b, int ldb,
+                                  double *__restrict__ lam) {
+  const int j = blockIdx.x;
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < b; i += blockDim.x) acc += V[(size_t)j * ldb + i] * B[(size_t)j * ldb + i];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = blockDim.x >> 1; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) lam[j] = red[0];
+}
+
+// W(i, j) = rowscale[i] * V(i, perm[j]) * scale[j]   (b x ncols)
+__global__ void permute_scale_kernel(const double *__restrict__ V, int ldv, int b, const int *__restrict__ perm,
+                                     const double *__restrict__ scale, const double *__restrict__ rowscale,
+                                     int ncols, double *__restrict__ W, int ldw) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)b * ncols) return;
+  const int i = (int)(e % b), j = (int)(e / b);
+  double v = V[(size_t)perm[j] * ldv + i];
+  if (scale) v *= scale[j];
+  if (rowscale) v *= rowscale[i];
+  W[(size_t)j * ldw + i] = v;
+}
+
+// S <- D S D with D = diag(1/sqrt(S_jj)): the Gram matrix of the column-normalised block
+__global__ void sym_scale_diag_kernel(const double *__restrict__ S, int b, double *__restrict__ dinv) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= b) return;
+  const double d = S[(size_t)j * b + j];
+  dinv[j] = d > 0.0 ? 1.0 / __builtin_sqrt(d) : 0.0;
+}
+__global__ void sym_scale_apply_kernel(double *__restrict__ S, int b, const double *__restrict__ dinv) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)b * b) return;
+  const int i = (int)(e % b), j = (int)(e / b);
+  S[e] = S[e] * dinv[i] * dinv[j];
+}
+
+// res[j] = | Z(:,j) - theta_j Q(:,j) |_2 , j < K ; also column norms of Q when Z == nullptr
+__global__ void resid_kernel(const double *__restrict__ Z, const double *__restrict__ Q, int s, int ld,
+                             const double *__restrict__ theta, double *__restrict__ res) {
+  const int j = blockIdx.x;
+  __shared__ double red[256];
+  double acc = 0.0;
+  for (int i = threadIdx.x; i < s; i += blockDim.x) {
+    const double q = Q[(size_t)j * ld + i];
+    const double d = Z ? Z[(size_t)j * ld + i] - theta[j] * q : q;
+    acc = __builtin_fma(d, d, acc);
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = blockDim.x >> 1; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) res[j] = __builtin_sqrt(red[0]);
+}
+
+// ------------------------------------------------------------------------------------------
+// host orchestration
+// ------------------------------------------------------------------------------------------
+struct JacobiPlan { int w, nbc, nt; size_t lds; };
+
+static JacobiPlan jacobi_plan(int b) {
+  JacobiPlan p;
+  // 2w columns of B and of V, each b+16 doubles, must fit ~150 KB of LDS
+  int w = (int)((150 * 1024) / (sizeof(double) * 4 * (size_t)(b + 16)));
+  int pw = 1;
+  while (pw * 2 <= w && pw < 32) pw *= 2;
+  p.w = pw;
+  p.nbc = (b + p.w - 1) / p.w;
+  if (p.nbc & 1) ++p.nbc;
+  if (p.nbc < 2) p.nbc = 2;
+  p.nt = 256;
+  p.lds = sizeof(double) * 4 * (size_t)p.w * (b + 16);
+  return p;
+}
+
+struct EigWork {
+  // big (s x b) buffers
+  double *Q, *Y, *Yp, *Z;
+  // small (b x b)
+  double *T, *JB, *JV, *W;
+  double *lam, *scale, *res, *dinv, *gemm_ws;
+  int *perm, *flags;
+  size_t gemm_ws_elems;
+};
+
+static size_t align_up(size_t x) { return (x + 255) / 256 * 256; }
+
+static int eig_block_size(int s, int K) {
+  int guard = K / 4;
+  if (guard < 24) guard = 24;
+  int b = K + guard;
+  b = (b + 15) / 16 * 16;
+  if (b > s) b = s;
+  return b;
+}
+
+static bool eig_use_dense(int s, int K) {
+  const int b = eig_block_size(s, K);
+  return K >= s || s <= 256 || 2 * b >= s;
+}
+
+static size_t eig_gemm_ws_elems(int s, int b) {
+  // split-K partials: the s x b products use up to 8 splits, the b x b ones up to 128
+  size_t a = (size_t)8 * s * b, c = (size_t)128 * b * b;
+  return a > c ? a : c;
+}
+
+static size_t eig_workspace_bytes(int s, int K) {
+  const bool dense = eig_use_dense(s, K);
+  const int b = dense ? s : eig_block_size(s, K);
+  size_t tot = 0;
+  if (!dense) tot += 4 * align_up(sizeof(double) * (size_t)s * b);
+  tot += 4 * align_up(sizeof(double) * (size_t)b * b);
+  tot += 4 * align_up(sizeof(double) * (size_t)b);
+  tot += align_up(sizeof(int) * (size_t)b) + align_up(sizeof(int) * 16);
+  if (!dense) tot += align_up(sizeof(double) * eig_gemm_ws_elems(s, b));
+  return tot + 1024;
+}
+
+// symmetric eigendecomposition of the b x b matrix T (device): on return JV holds eigenvectors,
+// h_lam the eigenvalues (unsorted, host copy).  Synchronises the stream.
+static int jacobi_eig(hipStream_t st, const double *T, int ldt, int b, EigWork &w, std::vector<double> &h_lam,
+                      int *sweeps_out) {
+  const JacobiPlan p = jacobi_plan(b);
+  if (p.lds > 48 * 1024)
+    FLGP_HIP(hipFuncSetAttribute((const void *)jac_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)p.lds));
+  hipLaunchKernelGGL(jac_init_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, T, ldt, b, w.JB, w.JV, b,
+                     w.flags);
+  FLGP_HIP(hipMemsetAsync(w.flags + 2, 0, sizeof(int), st));
+  FLGP_TRY(check_launch("jac_init_kernel"));
+  const int max_sweeps = 30;
+  const double tol = 1e-15;
+  int h_flags[4] = {0, 0, 0, 0};
+  for (int sw = 0; sw < max_sweeps; ++sw) {
+    for (int round = 0; round < p.nbc - 1; ++round) {
+      hipLaunchKernelGGL(jac_round_kernel, dim3(p.nbc / 2), dim3(p.nt), p.lds, st, w.JB, w.JV, b, b, p.w, p.nbc,
+                         round, tol, w.flags);
+    }
+    hipLaunchKernelGGL(jac_sweep_end_kernel, dim3(1), dim3(64), 0, st, w.flags);
+    FLGP_TRY(check_launch("jac_round_kernel"));
+    if (sw >= 2) {  // from the third sweep on, ask the device whether it is done
+      FLGP_HIP(hipMemcpyAsync(h_flags, w.flags, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
+      FLGP_HIP(hipStreamSynchronize(st));
+      if (h_flags[1]) break;
+    }
+  }
+  hipLaunchKernelGGL(jac_values_kernel, dim3(b), dim3(256), 0, st, w.JB, w.JV, b, b, w.lam);
+  FLGP_TRY(check_launch("jac_values_kernel"));
+  h_lam.resize(b);
+  FLGP_HIP(hipMemcpyAsync(h_lam.data(), w.lam, sizeof(double) * b, hipMemcpyDeviceToHost, st));
+  FLGP_HIP(hipMemcpyAsync(h_flags, w.flags, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
+  FLGP_HIP(hipStreamSynchronize(st));
+  if (sweeps_out) *sweeps_out = h_flags[2];
+  if (!h_flags[1]) {
+    set_error("block Jacobi did not converge in %d sweeps (b=%d)", max_sweeps, b);
+    return FLGP_ERR_NOCONV;
+  }
+  return FLGP_OK;
+}
+
+// W = JV(:, order) * diag(scale), order = eigenvalues descending
+static int sorted_basis(hipStream_t st, const std::vector<double> &lam, const std::vector<double> *scale, int b,
+                        int ncols, EigWork &w, std::vector<int> &order, const double *d_rowscale = nullptr) {
+  order.resize(b);
+  for (int j = 0; j < b; ++j) order[j] = j;
+  std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return lam[x] > lam[y]; });
+  FLGP_HIP(hipMemcpyAsync(w.perm, order.data(), sizeof(int) * ncols, hipMemcpyHostToDevice, st));
+  if (scale) FLGP_HIP(hipMemcpyAsync(w.scale, scale->data(), sizeof(double) * ncols, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(permute_scale_kernel, dim3(ceil_div((long)b * ncols, 256)), dim3(256), 0, st, w.JV, b, b,
+                     w.perm, scale ? w.scale : nullptr, d_rowscale, ncols, w.W, b);
+  FLGP_TRY(check_launch("permute_scale_kernel"));
+  FLGP_HIP(hipStreamSynchronize(st));  // order / scale are host vectors that may die after return
+  return FLGP_OK;
+}
+
+}  // namespace flgp
+
+using namespace flgp;
+
+extern "C" size_t flgp_dev_eig_workspace(int s, int K) {
+  if (K < 0 || K > s) K = s;
+  return eig_workspace_bytes(s, K);
+}
+
+extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s, int K, double tol,
+                                 double *d_values, double *dV, int ldv, void *d_work, size_t work_bytes,
+                                 int *info) {
+  hipStream_t st = (hipStream_t)stream;
+  FLGP_REQUIRE(s >= 1 && ldg >= s && ldv >= s, "eig: bad shape");
+  if (K < 0) K = s;
+  FLGP_REQUIRE(K >= 1 && K <= s, "eig: need 1 <= K <= s (K=%d, s=%d)", K, s);
+  FLGP_REQUIRE(work_bytes >= eig_workspace_bytes(s, K), "eig: workspace too small");
+  if (tol <= 0.0) tol = 1e-11;
+  const bool dense = eig_use_dense(s, K);
+  const int b = dense ? s : eig_block_size(s, K);
+  FLGP_REQUIRE(!dense || s <= 4096, "eig: the full decomposition (K == s, or K close to s) is built for s <= 4096");
+
+  // carve the workspace
+  EigWork w;
+  char *p = (char *)d_work;
+  auto take = [&](size_t bytes) { char *q = p; p += align_up(bytes); return q; };
+  const size_t big = sizeof(double) * (size_t)s * b;
+  if (!dense) { w.Q = (double *)take(big); w.Y = (double *)take(big); w.Yp = (double *)take(big); w.Z = (double *)take(big); }
+  else { w.Q = w.Y = w.Yp = w.Z = nullptr; }
+  const size_t small = sizeof(double) * (size_t)b * b;
+  w.T = (double *)take(small); w.JB = (double *)take(small); w.JV = (double *)take(small); w.W = (double *)take(small);
+  w.lam = (double *)take(sizeof(double) * b); w.scale = (double *)take(sizeof(double) * b);
+  w.res = (double *)take(sizeof(double) * b); w.dinv = (double *)take(sizeof(double) * b);
+  w.perm = (int *)take(sizeof(int) * b); w.flags = (int *)take(sizeof(int) * 16);
+  w.gemm_ws_elems = dense ? 0 : eig_gemm_ws_elems(s, b);
+  w.gemm_ws = dense ? nullptr : (double *)take(sizeof(double) * w.gemm_ws_elems);
+
+  std::vector<double> lam;
+  std::vector<int> order;
+  int sweeps = 0;
+  if (info) { info[0] = 0; info[1] = 0; info[2] = 0; }
+
+  if (dense) {
+    // full symmetric eigendecomposition of G itself (the K == s branch, src/TruncatedSVD.cpp:17-20)
+    FLGP_TRY(jacobi_eig(st, dG, ldg, s, w, lam, &sweeps));
+    FLGP_TRY(sorted_basis(st, lam, nullptr, s, K, w, order));
+    std::vector<double> vals(K);
+    for (int j = 0; j < K; ++j) vals[j] = lam[order[j]];
+    FLGP_HIP(hipMemcpyAsync(d_values, vals.data(), sizeof(double) * K, hipMemcpyHostToDevice, st));
+    FLGP_HIP(hipMemcpy2DAsync(dV, sizeof(double) * ldv, w.W, sizeof(double) * s, sizeof(double) * s, K,
+                              hipMemcpyDeviceToDevice, st));
+    FLGP_HIP(hipStreamSynchronize(st));
+    if (info) { info[0] = sweeps; info[2] = 1; }
+    return FLGP_OK;
+  }
+
+  const long tot = (long)s * b;
+  auto gemmG = [&](const double *Xin, double alpha, double beta, const double *E, double gamma, const double *E2,
+                   double *out) {  // out = alpha G Xin + beta E + gamma E2   (s x b)
+    return gemm_launch(st, s, b, s, alpha, dG, 1, ldg, Xin, 1, s, beta, E, 1, s, out, 1, s, w.gemm_ws,
+                       w.gemm_ws_elems, gamma, E2);
+  };
+  auto gram_small = [&](const double *Xa, const double *Xb, double *out) {  // out = Xa^T Xb   (b x b)
+    return gemm_launch(st, b, b, s, 1.0, Xa, s, 1, Xb, 1, s, 0.0, nullptr, 0, 0, out, 1, b, w.gemm_ws,
+                       w.gemm_ws_elems, 0.0, nullptr);
+  };
+  auto rotate = [&](const double *Xin, const double *Wm, double *out) {  // out = Xin Wm   (s x b)(b x b)
+    return gemm_launch(st, s, b, b, 1.0, Xin, 1, s, Wm, 1, b, 0.0, nullptr, 0, 0, out, 1, s, nullptr, 0, 0.0,
+                       nullptr);
+  };
+  // orthonormalise the columns of Yin into Qout ("SVQB" on the column-normalised block, so that
+  // the widely different column norms a Chebyshev filter leaves behind do not enter the
+  // conditioning of the Gram matrix); returns the condition estimate of the scaled Gram matrix
+  auto orth = [&](const double *Yin, double *Qout, double *cond_out) -> int {
+    FLGP_TRY(gram_small(Yin, Yin, w.T));
+    hipLaunchKernelGGL(sym_scale_diag_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, st, w.T, b, w.dinv);
+    hipLaunchKernelGGL(sym_scale_apply_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, w.T, b, w.dinv);
+    FLGP_TRY(check_launch("sym_scale_kernel"));
+    FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps));
+    double lmax = 0.0;
+    for (int j = 0; j < b; ++j) lmax = std::max(lmax, lam[j]);
+    std::vector<int> ord(b);
+    for (int j = 0; j < b; ++j) ord[j] = j;
+    std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return lam[x] > lam[y]; });
+    std::vector<double> sc(b);
+    const double floor_ = lmax * 1e-28;
+    double lmin = lmax;
+    for (int j = 0; j < b; ++j) {
+      const double l = std::max(lam[ord[j]], floor_);
+      lmin = std::min(lmin, l);
+      sc[j] = 1.0 / std::sqrt(l);
+    }
+    if (cond_out) *cond_out = (lmin > 0.0) ? lmax / lmin : 1e300;
+    FLGP_TRY(sorted_basis(st, lam, &sc, b, b, w, order, w.dinv));
+    return rotate(Yin, w.W, Qout);
+  };
+
+  // ---- start block, orthonormalised twice.  Four s x b buffers rotate through the roles
+  //      Q (orthonormal block) and three free ones.
+  double *Q = w.Q, *F[3] = {w.Y, w.Yp, w.Z};
+  hipLaunchKernelGGL(eig_init_q_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, st, F[0], s, b, s);
+  FLGP_TRY(check_launch("eig_init_q_kernel"));
+  double cond = 0.0;
+  FLGP_TRY(orth(F[0], F[1], &cond));
+  FLGP_TRY(orth(F[1], Q, &cond));
+
+  std::vector<double> theta(b), res(K);
+  int gprods = 0, it = 0;
+  const int max_it = 80;
+  bool converged = false;
+  double *result = nullptr;
+  for (it = 0; it < max_it; ++it) {
+    double *Z = F[0], *A = F[1], *B = F[2];
+    // ---- Rayleigh-Ritz on span(Q): Z = G Q, T = Q^T Z, T = W Th W^T
+    FLGP_TRY(gemmG(Q, 1.0, 0.0, nullptr, 0.0, nullptr, Z));
+    ++gprods;
+    FLGP_TRY(gram_small(Q, Z, w.T));
+    FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps));
+    FLGP_TRY(sorted_basis(st, lam, nullptr, b, b, w, order));
+    for (int j = 0; j < b; ++j) theta[j] = lam[order[j]];
+    FLGP_TRY(rotate(Q, w.W, A));   // A = Ritz vectors
+    FLGP_TRY(rotate(Z, w.W, B));   // B = G * Ritz vectors
+    // ---- residuals of the K wanted pairs
+    FLGP_HIP(hipMemcpyAsync(w.lam, theta.data(), sizeof(double) * b, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(resid_kernel, dim3(K), dim3(256), 0, st, B, A, s, s, w.lam, w.res);
+    FLGP_TRY(check_launch("resid_kernel"));
+    FLGP_HIP(hipMemcpyAsync(res.data(), w.res, sizeof(double) * K, hipMemcpyDeviceToHost, st));
+    FLGP_HIP(hipStreamSynchronize(st));
+    double rmax = 0.0;
+    for (int j = 0; j < K; ++j) rmax = std::max(rmax, res[j]);
+    const double top = std::max(theta[0], 1e-300);
+    if (tuning("eig_verbose", 0))
+      fprintf(stderr, "[flgp eig] it=%d gprods=%d theta0=%.15g thetaK=%.6g cut=%.6g rmax=%.3e cond=%.2e sweeps=%d\n",
+              it, gprods, theta[0], theta[K - 1], theta[b - 1], rmax, cond, sweeps);
+    if (rmax <= tol * top) { converged = true; result = A; break; }
+
+    // ---- Chebyshev filter on [0, cut], scaled to 1 at the top Ritz value
+    double cut = theta[b - 1];
+    if (!(cut > 0.0)) cut = 1e-3 * top;
+    if (cut > 0.999 * top) cut = 0.999 * top;   // degenerate block: keep a valid interval
+    const double e = 0.5 * cut, c = 0.5 * cut;
+    const double g1 = (top - c) / e;            // >= 1
+    // degree: amplification T_m(g1) of the top direction capped per outer iteration
+    // (gentler while the block is still far from the invariant subspace)
+    const double amp = (it < 2) ? 1e3 : 1e7;
+    int m = (int)std::floor(std::acosh(amp) / std::acosh(std::max(g1, 1.0 + 1e-12)));
+    m = std::max(2, std::min(m, 40));
+    const double sigma1 = e / (top - c);
+    double sigma = sigma1;
+    // degree 1: Y = (sigma1/e) (G A - c A) = (sigma1/e) (B - c A), into the free buffer Q
+    double *prev = A, *cur = Q, *next = Z;
+    hipLaunchKernelGGL(eig_axpby_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, st, sigma1 / e, B,
+                       -sigma1 * c / e, A, cur, tot);
+    FLGP_TRY(check_launch("eig_axpby_kernel"));
+    for (int deg = 2; deg <= m; ++deg) {
+      const double sn = 1.0 / (2.0 / sigma1 - sigma);
+      // next = (2 sn / e) (G cur - c cur) - sigma sn prev
+      FLGP_TRY(gemmG(cur, 2.0 * sn / e, -2.0 * sn * c / e, cur, -sigma * sn, prev, next));
+      ++gprods;
+      double *t3 = prev; prev = cur; cur = next; next = t3;
+      sigma = sn;
+    }
+    // ---- orthonormalise the filtered block (B is free by now; twice if ill-conditioned)
+    FLGP_TRY(orth(cur, B, &cond));
+    double *R = B;
+    if (cond > 1e8) {
+      FLGP_TRY(orth(B, prev, &cond));
+      R = prev;
+    }
+    // new roles: Q = R, the other three buffers are free
+    double *pool[4] = {A, Q, Z, B};
+    int nf = 0;
+    for (int q = 0; q < 4; ++q)
+      if (pool[q] != R) F[nf++] = pool[q];
+    Q = R;
+  }
+  if (info) { info[0] = it; info[1] = gprods; info[2] = 0; }
+  if (!converged) {
+    set_error("eigensolver: %d of the residuals still above %.1e after %d outer iterations", K, tol, max_it);
+    return FLGP_ERR_NOCONV;
+  }
+  FLGP_HIP(hipMemcpyAsync(d_values, theta.data(), sizeof(double) * K, hipMemcpyHostToDevice, st));
+  FLGP_HIP(hipMemcpy2DAsync(dV, sizeof(double) * ldv, result, sizeof(double) * s, sizeof(double) * s, K,
+                            hipMemcpyDeviceToDevice, st));
+  FLGP_HIP(hipStreamSynchronize(st));
+  return FLGP_OK;
+}

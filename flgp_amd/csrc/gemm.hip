@@ -1,0 +1,283 @@
+// k7: fp64 MFMA GEMM (v_mfma_f64_16x16x4_f64) and the heat-kernel contraction built on it.
+//
+//   flgp_dev_gemm : C(i,j) = alpha * sum_k A(i,k) B(k,j) + beta * E(i,j), arbitrary element
+//                   strides, optional split-K with a fixed-order reduction (deterministic).
+//   flgp_dev_hk   : H = V[idx0,0:K] diag(exp(-t(1-values))) V[idx1,0:K]^T
+//                   (HK_from_spectrum_cpp, reference src/Spectrum.cpp:83-94): the diagonal is
+//                   folded into the small operand once, then one GEMM streams V once and
+//                   writes H once.
+//
+// Tiling (gfx950): 128 x 128 block tile, BK = 16, 256 threads = 4 waves in 2 x 2, each wave a
+// 64 x 64 sub-tile = 4 x 4 MFMA tiles (16 accumulators x 4 f64 = 128 VGPRs).  Operand tiles go
+// global -> registers (prefetched one tile ahead, so HBM latency hides under the MFMAs) -> LDS
+// as [k][row] with the row stride padded by 16 doubles (k and k+1 then sit 32 banks apart and
+// the ds_read_b64 fragment reads are conflict free).  The fp64 MFMA is slow enough per
+// instruction (2048 flop per wave per ~64 cycles) that 8 fragment reads per 16 MFMAs keep the
+// matrix pipe fed; two blocks per CU cover the barrier bubbles.
+//
+// Layout trick: the MFMA result puts the tile COLUMN on lane&15, so for coalesced stores the
+// host wrapper orients the problem (computing C^T = B^T A^T when C is column-major) such that
+// the memory-contiguous output dimension is always the kernel's column dimension.
+#include "common.h"
+
+namespace flgp {
+
+typedef double d4 __attribute__((ext_vector_type(4)));
+
+constexpr int GB = 128;        // block tile (rows and cols)
+constexpr int GK = 16;         // k depth per stage
+constexpr int GLD = GB + 16;   // padded LDS row stride (doubles)
+
+struct GemmArgs {
+  int M, N, Kd;
+  const double *A; long a_is, a_ks;   // A(i,k)
+  const double *B; long b_ks, b_js;   // B(k,j)
+  double alpha, beta, gamma;
+  const double *E; long e_is, e_js;    // + beta * E(i,j)
+  const double *E2;                    // + gamma * E2(i,j), same strides as E
+  double *C; long c_is, c_js;
+  int ksplit_len;                     // k range per blockIdx.z (multiple of GK); partials when gridDim.z > 1
+  double *part;                       // [z][M][N] row-major partials
+};
+
+// load a 128(rows) x 16(k) operand tile into registers: 8 elements per thread.
+// ROWC: element (row, k) at base[row*rs + k*ks]; mapping 0 (row-contiguous) or 1 (k-contiguous / generic)
+__device__ __forceinline__ void tile_load(double (&reg)[8], const double *__restrict__ base, long rs, long ks,
+                                          int row0, int nrows, int k0, int kend, bool row_contig, int tid) {
+  if (row_contig) {
+    const int row = row0 + (tid & 127);
+    const int kb = tid >> 7;
+#pragma unroll
+    for (int rep = 0; rep < 8; ++rep) {
+      const int k = k0 + kb + 2 * rep;
+      reg[rep] = (row < nrows && k < kend) ? base[(size_t)row * rs + (size_t)k * ks] : 0.0;
+    }
+  } else {
+    const int k = k0 + (tid & 15);
+    const int rb = tid >> 4;
+#pragma unroll
+    for (int rep = 0; rep < 8; ++rep) {
+      const int row = row0 + rb + 16 * rep;
+      reg[rep] = (row < nrows && k < kend) ? base[(size_t)row * rs + (size_t)k * ks] : 0.0;
+    }
+  }
+}
+
+__device__ __forceinline__ void tile_store(const double (&reg)[8], double *__restrict__ lds, bool row_contig, int tid) {
+  if (row_contig) {
+    const int row = tid & 127, kb = tid >> 7;
+#pragma unroll
+    for (int rep = 0; rep < 8; ++rep) lds[(kb + 2 * rep) * GLD + row] = reg[rep];
+  } else {
+    const int k = tid & 15, rb = tid >> 4;
+#pragma unroll
+    for (int rep = 0; rep < 8; ++rep) lds[k * GLD + rb + 16 * rep] = reg[rep];
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
+  __shared__ double As[GK * GLD];
+  __shared__ double Bs[GK * GLD];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+
+  // XCD-aware tile order: consecutive block ids share an XCD every 8; give each XCD a band of tiles
+  const int ntm = (g.M + GB - 1) / GB, ntn = (g.N + GB - 1) / GB;
+  const int nt = ntm * ntn;
+  int bid = blockIdx.x;
+  {
+    const int q = nt / 8, rem = nt % 8, xcd = bid % 8;
+    bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + bid / 8;
+  }
+  // the shorter tile dimension runs fastest, so the blocks that are resident together on an XCD
+  // share the long operand's panel through L2 and the short operand stays L2 resident
+  const int tm = (ntm <= ntn) ? bid % ntm : bid / ntn;
+  const int tn = (ntm <= ntn) ? bid / ntm : bid % ntn;
+  const int row0 = tm * GB, col0 = tn * GB;
+
+  const int kbeg = blockIdx.z * g.ksplit_len;
+  int kend = kbeg + g.ksplit_len;
+  if (kend > g.Kd) kend = g.Kd;
+
+  const bool a_rc = (g.a_is == 1), b_rc = (g.b_js == 1);
+  d4 acc[4][4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
+
+  double ra[8], rb[8];
+  tile_load(ra, g.A, g.a_is, g.a_ks, row0, g.M, kbeg, kend, a_rc, tid);
+  tile_load(rb, g.B, g.b_js, g.b_ks, col0, g.N, kbeg, kend, b_rc, tid);
+
+  const int fr = lane & 15, fk = lane >> 4;
+  for (int k0 = kbeg; k0 < kend; k0 += GK) {
+    __syncthreads();  // previous stage's fragment reads are done
+    tile_store(ra, As, a_rc, tid);
+    tile_store(rb, Bs, b_rc, tid);
+    __syncthreads();
+    if (k0 + GK < kend) {  // prefetch the next stage while this one computes
+      tile_load(ra, g.A, g.a_is, g.a_ks, row0, g.M, k0 + GK, kend, a_rc, tid);
+      tile_load(rb, g.B, g.b_js, g.b_ks, col0, g.N, k0 + GK, kend, b_rc, tid);
+    }
+#pragma unroll
+    for (int kk = 0; kk < GK; kk += 4) {
+      double fa[4], fb[4];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) fa[mi] = As[(kk + fk) * GLD + wr + mi * 16 + fr];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) fb[ni] = Bs[(kk + fk) * GLD + wc + ni * 16 + fr];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+          acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+    }
+  }
+
+  // epilogue: D(row = (lane>>4) + 4*reg, col = lane&15) of each 16x16 tile
+  const bool partial = gridDim.z > 1;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi) {
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) {
+      const int j = col0 + wc + ni * 16 + fr;
+#pragma unroll
+      for (int reg = 0; reg < 4; ++reg) {
+        const int i = row0 + wr + mi * 16 + fk + 4 * reg;
+        if (i < g.M && j < g.N) {
+          const double v = acc[mi][ni][reg];
+          if (partial) {
+            g.part[((size_t)blockIdx.z * g.M + i) * g.N + j] = v;
+          } else {
+            double o = g.alpha * v;
+            if (g.E) o += g.beta * g.E[(size_t)i * g.e_is + (size_t)j * g.e_js];
+            if (g.E2) o += g.gamma * g.E2[(size_t)i * g.e_is + (size_t)j * g.e_js];
+            g.C[(size_t)i * g.c_is + (size_t)j * g.c_js] = o;
+          }
+        }
+      }
+    }
+  }
+}
+
+__global__ void splitk_reduce_kernel(GemmArgs g, int nsplit) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long)g.M * g.N) return;
+  const int i = (int)(idx / g.N), j = (int)(idx % g.N);
+  double v = 0.0;
+  for (int z = 0; z < nsplit; ++z) v += g.part[((size_t)z * g.M + i) * g.N + j];  // fixed order
+  double o = g.alpha * v;
+  if (g.E) o += g.beta * g.E[(size_t)i * g.e_is + (size_t)j * g.e_js];
+  if (g.E2) o += g.gamma * g.E2[(size_t)i * g.e_is + (size_t)j * g.e_js];
+  g.C[(size_t)i * g.c_is + (size_t)j * g.c_js] = o;
+}
+
+int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double *A, long a_is, long a_ks,
+                const double *B, long b_ks, long b_js, double beta, const double *E, long e_is, long e_js,
+                double *C, long c_is, long c_js, double *work, size_t work_elems, double gamma,
+                const double *E2) {
+  if (M <= 0 || N <= 0) return FLGP_OK;
+  GemmArgs g;
+  // orient so that the contiguous output dimension is the kernel's column dimension
+  if (c_is == 1 && c_js != 1) {
+    g.M = N; g.N = M; g.Kd = Kd;
+    g.A = B; g.a_is = b_js; g.a_ks = b_ks;
+    g.B = A; g.b_ks = a_ks; g.b_js = a_is;
+    g.E = E; g.e_is = e_js; g.e_js = e_is;
+    g.C = C; g.c_is = c_js; g.c_js = c_is;
+  } else {
+    g.M = M; g.N = N; g.Kd = Kd;
+    g.A = A; g.a_is = a_is; g.a_ks = a_ks;
+    g.B = B; g.b_ks = b_ks; g.b_js = b_js;
+    g.E = E; g.e_is = e_is; g.e_js = e_js;
+    g.C = C; g.c_is = c_is; g.c_js = c_js;
+  }
+  g.alpha = alpha; g.beta = beta; g.gamma = gamma;
+  g.E2 = (gamma == 0.0) ? nullptr : E2;
+  if (beta == 0.0) g.E = nullptr;
+  const int ntiles = ceil_div(g.M, GB) * ceil_div(g.N, GB);
+  int nsplit = 1;
+  if (work && ntiles < 256 && Kd >= 8 * GK) {
+    nsplit = 512 / ntiles;
+    const int maxk = Kd / (2 * GK);
+    if (nsplit > maxk) nsplit = maxk;
+    const size_t per = (size_t)g.M * g.N;
+    if ((size_t)nsplit * per > work_elems) nsplit = (int)(work_elems / per);
+    if (nsplit < 1) nsplit = 1;
+  }
+  int klen = ceil_div(Kd > 0 ? Kd : 1, nsplit);
+  klen = (klen + GK - 1) / GK * GK;
+  nsplit = ceil_div(Kd > 0 ? Kd : 1, klen);
+  g.ksplit_len = klen;
+  g.part = work;
+  hipLaunchKernelGGL(gemm_f64_kernel, dim3(ntiles, 1, nsplit), dim3(256), 0, st, g);
+  FLGP_TRY(check_launch("gemm_f64_kernel"));
+  if (nsplit > 1) {
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div((long)g.M * g.N, 256)), dim3(256), 0, st, g, nsplit);
+    FLGP_TRY(check_launch("splitk_reduce_kernel"));
+  }
+  return FLGP_OK;
+}
+
+// Vw(b,k) = exp(-t (1 - values_k)) * V1(row(b), k), stored b-contiguous: Vw[b + k*n1]
+__global__ void hk_scale_kernel(const double *__restrict__ values, int K, double t, const double *__restrict__ V1,
+                                int ld1, const int *__restrict__ idx1, int row0, int n1, double *__restrict__ Vw) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)n1 * K) return;
+  const int b = (int)(e % n1), k = (int)(e / n1);
+  const int row = idx1 ? idx1[b] : row0 + b;
+  const double w = exp(-t * (1.0 - values[k]));  // src/Spectrum.cpp:86,90
+  Vw[e] = V1[(size_t)k * ld1 + row] * w;
+}
+
+__global__ void gather_rows_kernel(const double *__restrict__ V, int ld, const int *__restrict__ idx, int n0, int K,
+                                   double *__restrict__ out) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)n0 * K) return;
+  const int a = (int)(e % n0), k = (int)(e / n0);
+  out[e] = V[(size_t)k * ld + idx[a]];
+}
+
+}  // namespace flgp
+
+using namespace flgp;
+
+extern "C" int flgp_dev_gemm(void *stream, int M, int N, int Kd, double alpha, const double *A, long a_is,
+                             long a_ks, const double *B, long b_ks, long b_js, double beta, const double *E,
+                             long e_is, long e_js, double *C, long c_is, long c_js, double *d_work,
+                             size_t work_elems) {
+  FLGP_REQUIRE(M >= 0 && N >= 0 && Kd >= 0 && A && B && C, "gemm: bad arguments");
+  return gemm_launch((hipStream_t)stream, M, N, Kd, alpha, A, a_is, a_ks, B, b_ks, b_js, beta, E, e_is, e_js, C,
+                     c_is, c_js, d_work, work_elems, 0.0, nullptr);
+}
+
+extern "C" size_t flgp_dev_hk_workspace(int n0, int n1, int K, int gather0) {
+  return sizeof(double) * ((size_t)n1 * K + (gather0 ? (size_t)n0 * K : 0)) + 256;
+}
+
+extern "C" int flgp_dev_hk(void *stream, const double *d_values, int K, double t, const double *dV0, int ld0,
+                           const int *d_idx0, int row0_0, int n0, const double *dV1, int ld1, const int *d_idx1,
+                           int row0_1, int n1, double *dH, int ldh, double *d_work) {
+  hipStream_t st = (hipStream_t)stream;
+  FLGP_REQUIRE(K >= 1 && n0 >= 0 && n1 >= 0 && ldh >= n0, "HK: bad shape");
+  if (n0 == 0 || n1 == 0) return FLGP_OK;
+  double *Vw = d_work;
+  hipLaunchKernelGGL(hk_scale_kernel, dim3(ceil_div((long)n1 * K, 256)), dim3(256), 0, st, d_values, K, t, dV1, ld1,
+                     d_idx1, row0_1, n1, Vw);
+  FLGP_TRY(check_launch("hk_scale_kernel"));
+  const double *V0 = dV0 + row0_0;
+  long v0_ld = ld0;
+  if (d_idx0) {  // general row gather (mat_indexing, src/Utils.h:130-137); callers normally pass ranges
+    double *G0 = d_work + (size_t)n1 * K;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div((long)n0 * K, 256)), dim3(256), 0, st, dV0, ld0, d_idx0,
+                       n0, K, G0);
+    FLGP_TRY(check_launch("gather_rows_kernel"));
+    V0 = G0;
+    v0_ld = n0;
+  }
+  // H(a,b) = sum_k V0(a,k) Vw(b,k)
+  return gemm_launch(st, n0, n1, K, 1.0, V0, 1, v0_ld, Vw, n1, 1, 0.0, nullptr, 0, 0, dH, 1, ldh, nullptr, 0, 0.0,
+                     nullptr);
+}

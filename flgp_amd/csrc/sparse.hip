@@ -1,0 +1,332 @@
+// k5 and the sparse half of k6: everything that touches the n x s similarity matrix Z / A in
+// its ELL form (row-major idx[n][r], val[n][r], rows sorted by column).
+//
+//   - CSC view of the pattern by a stable counting sort (deterministic, rows ascending);
+//   - column sums in row-ascending order == `RowVectorXd::Ones(n) * Z` on a row-major sparse
+//     matrix (reference src/Utils.cpp:200,203, src/Spectrum.cpp:149), bit-exact vs the oracle;
+//   - column / row scalings of graphLaplacian_cpp (src/Utils.cpp:195-212) and of
+//     spectrum_from_Z_cpp (src/Spectrum.cpp:150);
+//   - Gram matrix G = A^T A in a fixed summation order (the s x s operator RSpectra::svds
+//     iterates on, src/TruncatedSVD.cpp:23-28);
+//   - u_k = A v_k / sigma_k * sqrt(n) (svds' left vectors + src/Spectrum.cpp:157-158).
+//
+// All of these are HBM / latency bound integer-and-fp64 streaming work: no MFMA here.
+#include "common.h"
+
+namespace flgp {
+
+// ----------------------------------------------------------------------------------------
+// CSC build: stable counting sort of the nnz = n*r entries by column.
+//   pass 1  per-chunk column histograms (LDS int atomics: counts are order independent)
+//   pass 2  per column: exclusive prefix over chunks, column totals
+//   pass 3  exclusive scan of the totals -> colptr
+//   pass 4  one wave per chunk walks its entries in order, 64 at a time; lanes that hit the
+//           same column in one step are ranked by lane id (ballot-built match mask), so the
+//           order inside a column is exactly the entry order == ascending row.
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void csc_hist_kernel(const int *__restrict__ ell_idx, long nnz, int s,
+                                                       int chunk, int *__restrict__ hist) {
+  extern __shared__ int lh[];
+  for (int j = threadIdx.x; j < s; j += blockDim.x) lh[j] = 0;
+  __syncthreads();
+  const long e0 = (long)blockIdx.x * chunk;
+  long e1 = e0 + chunk;
+  if (e1 > nnz) e1 = nnz;
+  for (long e = e0 + threadIdx.x; e < e1; e += blockDim.x) atomicAdd(&lh[ell_idx[e]], 1);
+  __syncthreads();
+  int *out = hist + (size_t)blockIdx.x * s;
+  for (int j = threadIdx.x; j < s; j += blockDim.x) out[j] = lh[j];
+}
+
+__global__ void csc_colscan_kernel(int *__restrict__ hist, int nchunks, int s, int *__restrict__ tot) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= s) return;
+  int run = 0;
+  for (int c = 0; c < nchunks; ++c) {
+    const int h = hist[(size_t)c * s + j];
+    hist[(size_t)c * s + j] = run;
+    run += h;
+  }
+  tot[j] = run;
+}
+
+// single-block exclusive scan of tot[0..s) -> colptr[0..s]
+__global__ __launch_bounds__(1024) void csc_scan_kernel(const int *__restrict__ tot, int s, int *__restrict__ colptr) {
+  __shared__ int part[1024];
+  const int t = threadIdx.x;
+  const int per = (s + 1023) / 1024;
+  const int lo = t * per, hi = (lo + per < s) ? lo + per : s;
+  int sum = 0;
+  for (int j = lo; j < hi; ++j) sum += tot[j];
+  part[t] = sum;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {
+    int v = (t >= off) ? part[t - off] : 0;
+    __syncthreads();
+    part[t] += v;
+    __syncthreads();
+  }
+  int run = (t == 0) ? 0 : part[t - 1];
+  for (int j = lo; j < hi; ++j) { colptr[j] = run; run += tot[j]; }
+  if (t == 1023) colptr[s] = part[1023];
+}
+
+__global__ __launch_bounds__(64) void csc_scatter_kernel(const int *__restrict__ ell_idx, long nnz, int s,
+                                                         int chunk, int nbits, const int *__restrict__ hist,
+                                                         const int *__restrict__ colptr, int *__restrict__ pos) {
+  extern __shared__ int cur[];  // running count per column inside this chunk
+  const int lane = threadIdx.x;
+  for (int j = lane; j < s; j += 64) cur[j] = 0;
+  __syncthreads();
+  const int *hoff = hist + (size_t)blockIdx.x * s;
+  const long e0 = (long)blockIdx.x * chunk;
+  long e1 = e0 + chunk;
+  if (e1 > nnz) e1 = nnz;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (long eb = e0; eb < e1; eb += 64) {
+    const long e = eb + lane;
+    const bool act = e < e1;
+    const int col = act ? ell_idx[e] : 0;
+    unsigned long long m = __ballot(act);
+    for (int b = 0; b < nbits; ++b) {
+      const bool bit = (col >> b) & 1;
+      const unsigned long long bal = __ballot(bit);
+      m &= bit ? bal : ~bal;
+    }
+    if (act) {
+      const int rank = __popcll(m & lt);
+      const int base = cur[col];
+      pos[(size_t)colptr[col] + hoff[col] + base + rank] = (int)e;
+      if (rank == 0) cur[col] = base + __popcll(m);  // one writer per column group; all read before (same instr)
+    }
+    __syncthreads();  // single wave: orders the LDS read-modify-write between steps
+  }
+}
+
+// colsum[j] = sum over the column's entries in ascending row order (one lane per column,
+// strictly sequential adds from 0.0: the oracle's / the reference's order)
+__global__ void colsum_kernel(const double *__restrict__ val, const int *__restrict__ colptr,
+                              const int *__restrict__ pos, int s, double *__restrict__ colsum) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= s) return;
+  double acc = 0.0;
+  const int p1 = colptr[j + 1];
+  for (int p = colptr[j]; p < p1; ++p) acc += val[pos[p]];
+  colsum[j] = acc;
+}
+
+__global__ void col_scale_kernel(const int *__restrict__ ell_idx, double *__restrict__ val, long nnz,
+                                 const double *__restrict__ colsum, const double *__restrict__ num_class,
+                                 int mode) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nnz) return;
+  const int j = ell_idx[e];
+  const double c = colsum[j];
+  double v = val[e];
+  if (mode == 0) {
+    v = v * (1.0 / (c + 1e-9));                    // src/Utils.cpp:201,204
+    if (num_class) v = v * num_class[j];           // src/Utils.cpp:205
+  } else {
+    v = v * (1.0 / __builtin_sqrt(__builtin_fabs(c) + 1e-9));  // src/Spectrum.cpp:150
+  }
+  val[e] = v;
+}
+
+__global__ void row_normalize_kernel(double *__restrict__ val, int n, int r) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double *row = val + (size_t)i * r;
+  double rs = 0.0;
+  for (int a = 0; a < r; ++a) rs += row[a];        // ascending column order (src/Utils.cpp:210)
+  const double inv = 1.0 / (rs + 1e-9);
+  for (int a = 0; a < r; ++a) row[a] = inv * row[a];  // src/Utils.cpp:211
+}
+
+// ----------------------------------------------------------------------------------------
+// Gram: one wave per column j1.  The wave owns row j1 of G in LDS (s doubles), walks the
+// column's entries in ascending row order, loads GR = 64/r rows of A at a time (memory-level
+// parallelism) and applies them to the LDS row one row after the other, so that every
+// G(j1, j2) is summed in ascending row order: deterministic, and identical to the oracle.
+// ----------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void gram_kernel(const int *__restrict__ ell_idx, const double *__restrict__ val,
+                                                  int s, int r, const int *__restrict__ colptr,
+                                                  const int *__restrict__ pos, double *__restrict__ G, int ldg) {
+  extern __shared__ double acc[];
+  const int lane = threadIdx.x;
+  const int j1 = blockIdx.x;
+  for (int j = lane; j < s; j += 64) acc[j] = 0.0;
+  __syncthreads();
+  const int GR = 64 / r;            // rows per step
+  const int sub = lane / r;         // which of the GR rows this lane serves
+  const int a = lane - sub * r;     // slot inside the row
+  const int p0 = colptr[j1], p1 = colptr[j1 + 1];
+  for (int pb = p0; pb < p1; pb += GR) {
+    const int p = pb + sub;
+    const bool act = (sub < GR) && (p < p1);
+    int j2 = 0;
+    double prod = 0.0;
+    if (act) {
+      const int e = pos[p];
+      const size_t rowbase = (size_t)(e / r) * r;
+      const double a1 = val[e];
+      j2 = ell_idx[rowbase + a];
+      prod = a1 * val[rowbase + a];
+    }
+    for (int q = 0; q < GR; ++q) {  // rows strictly in order; distinct j2 inside a row
+      if (act && sub == q) acc[j2] += prod;
+      __syncthreads();
+    }
+  }
+  double *out = G + (size_t)j1 * ldg;
+  for (int j = lane; j < s; j += 64) out[j] = acc[j];
+}
+
+// vectors(i,k) = (sum_a A(i,a) V(idx(i,a),k)) / sigma_k * scale ; sigma_k = sqrt(max(eig_k,0))
+__global__ __launch_bounds__(256) void u_recover_kernel(const int *__restrict__ ell_idx,
+                                                        const double *__restrict__ val, int n, int r,
+                                                        const double *__restrict__ V, int ldv,
+                                                        const double *__restrict__ eig, int K, double scale,
+                                                        double *__restrict__ out, int ldo) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int k0 = blockIdx.y * 8;
+  double acc[8];
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) acc[kk] = 0.0;
+  for (int a = 0; a < r; ++a) {  // a ascending per (i,k): the oracle's order; mul then add
+    const int id = ell_idx[(size_t)i * r + a];
+    const double va = val[(size_t)i * r + a];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk)
+      if (k0 + kk < K) acc[kk] += va * V[(size_t)(k0 + kk) * ldv + id];
+  }
+#pragma unroll
+  for (int kk = 0; kk < 8; ++kk) {
+    const int k = k0 + kk;
+    if (k < K) {
+      const double ev = eig[k];
+      const double sigma = __builtin_sqrt(ev > 0.0 ? ev : 0.0);
+      out[(size_t)k * ldo + i] = (acc[kk] / sigma) * scale;
+    }
+  }
+}
+
+__global__ void values_out_kernel(const double *__restrict__ eig, int K, int root, double *__restrict__ values) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= K) return;
+  const double ev = eig[k] > 0.0 ? eig[k] : 0.0;
+  values[k] = root ? __builtin_sqrt(ev) : ev;   // values = d^2 (src/TruncatedSVD.cpp:29), sqrt if root (src/Spectrum.cpp:153-155)
+}
+
+struct CscPlan {
+  int nchunks, chunk, nbits;
+  size_t hist_bytes, tot_bytes;
+};
+
+static CscPlan csc_plan(long nnz, int s) {
+  CscPlan p;
+  long nc = (nnz + 2047) / 2048;
+  if (nc > 2048) nc = 2048;
+  if (nc < 1) nc = 1;
+  long chunk = (nnz + nc - 1) / nc;
+  chunk = (chunk + 63) / 64 * 64;
+  if (chunk < 64) chunk = 64;
+  p.chunk = (int)chunk;
+  p.nchunks = (int)((nnz + chunk - 1) / chunk);
+  if (p.nchunks < 1) p.nchunks = 1;
+  p.nbits = 1;
+  while ((1 << p.nbits) < s) ++p.nbits;
+  p.hist_bytes = sizeof(int) * (size_t)p.nchunks * s;
+  p.tot_bytes = sizeof(int) * (size_t)s;
+  return p;
+}
+
+}  // namespace flgp
+
+using namespace flgp;
+
+extern "C" size_t flgp_dev_csc_workspace(int n, int s, int r) {
+  const CscPlan p = csc_plan((long)n * r, s);
+  return p.hist_bytes + p.tot_bytes + 256;
+}
+
+extern "C" int flgp_dev_csc_build(void *stream, const int *d_ell_idx, int n, int s, int r, int *d_colptr,
+                                  int *d_pos, void *d_work, size_t work_bytes) {
+  hipStream_t st = (hipStream_t)stream;
+  const long nnz = (long)n * r;
+  FLGP_REQUIRE(nnz < 2147483647L, "CSC: n*r = %ld does not fit int32 positions", nnz);
+  FLGP_REQUIRE(s >= 1 && s <= 32768, "CSC: kernels are built for s <= 32768 (got %d)", s);
+  FLGP_REQUIRE(work_bytes >= flgp_dev_csc_workspace(n, s, r), "CSC: workspace too small");
+  const CscPlan p = csc_plan(nnz, s);
+  int *hist = (int *)d_work;
+  int *tot = (int *)((char *)d_work + p.hist_bytes);
+  const size_t lds = sizeof(int) * (size_t)s;
+  if (lds > 48 * 1024) {
+    FLGP_HIP(hipFuncSetAttribute((const void *)csc_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    FLGP_HIP(hipFuncSetAttribute((const void *)csc_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  }
+  hipLaunchKernelGGL(csc_hist_kernel, dim3(p.nchunks), dim3(256), lds, st, d_ell_idx, nnz, s, p.chunk, hist);
+  FLGP_TRY(check_launch("csc_hist_kernel"));
+  hipLaunchKernelGGL(csc_colscan_kernel, dim3(ceil_div(s, 256)), dim3(256), 0, st, hist, p.nchunks, s, tot);
+  FLGP_TRY(check_launch("csc_colscan_kernel"));
+  hipLaunchKernelGGL(csc_scan_kernel, dim3(1), dim3(1024), 0, st, tot, s, d_colptr);
+  FLGP_TRY(check_launch("csc_scan_kernel"));
+  hipLaunchKernelGGL(csc_scatter_kernel, dim3(p.nchunks), dim3(64), lds, st, d_ell_idx, nnz, s, p.chunk, p.nbits,
+                     hist, d_colptr, d_pos);
+  return check_launch("csc_scatter_kernel");
+}
+
+extern "C" int flgp_dev_colsum(void *stream, const double *d_ell_val, const int *d_colptr, const int *d_pos,
+                               int s, double *d_colsum) {
+  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(s, 64)), dim3(64), 0, (hipStream_t)stream, d_ell_val, d_colptr,
+                     d_pos, s, d_colsum);
+  return check_launch("colsum_kernel");
+}
+
+extern "C" int flgp_dev_col_scale(void *stream, const int *d_ell_idx, double *d_ell_val, int n, int r,
+                                  const double *d_colsum, const double *d_num_class, int mode) {
+  FLGP_REQUIRE(mode == 0 || mode == 1, "col_scale: mode must be 0 or 1");
+  const long nnz = (long)n * r;
+  if (nnz == 0) return FLGP_OK;
+  hipLaunchKernelGGL(col_scale_kernel, dim3(ceil_div(nnz, 256)), dim3(256), 0, (hipStream_t)stream, d_ell_idx,
+                     d_ell_val, nnz, d_colsum, d_num_class, mode);
+  return check_launch("col_scale_kernel");
+}
+
+extern "C" int flgp_dev_row_normalize(void *stream, double *d_ell_val, int n, int r) {
+  if (n == 0) return FLGP_OK;
+  hipLaunchKernelGGL(row_normalize_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, d_ell_val,
+                     n, r);
+  return check_launch("row_normalize_kernel");
+}
+
+extern "C" int flgp_dev_gram(void *stream, const int *d_ell_idx, const double *d_ell_val, int n, int s, int r,
+                             const int *d_colptr, const int *d_pos, double *dG, int ldg) {
+  (void)n;
+  FLGP_REQUIRE(s >= 1 && s <= 20000, "Gram: kernel is built for s <= 20000 (got %d)", s);
+  FLGP_REQUIRE(r >= 1 && r <= FLGP_RMAX && ldg >= s, "Gram: bad r / ldg");
+  const size_t lds = sizeof(double) * (size_t)s;
+  if (lds > 48 * 1024)
+    FLGP_HIP(hipFuncSetAttribute((const void *)gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(gram_kernel, dim3(s), dim3(64), lds, (hipStream_t)stream, d_ell_idx, d_ell_val, s, r, d_colptr,
+                     d_pos, dG, ldg);
+  return check_launch("gram_kernel");
+}
+
+extern "C" int flgp_dev_u_recover(void *stream, const int *d_ell_idx, const double *d_ell_val, int n, int r,
+                                  const double *dV, int ldv, int s, const double *d_eig, int K, double scale,
+                                  int root, double *d_vectors, int ldo, double *d_values_out) {
+  (void)s;
+  hipStream_t st = (hipStream_t)stream;
+  FLGP_REQUIRE(r >= 1 && r <= FLGP_RMAX && K >= 1 && ldo >= n, "u_recover: bad shape");
+  if (n > 0) {
+    hipLaunchKernelGGL(u_recover_kernel, dim3(ceil_div(n, 256), ceil_div(K, 8)), dim3(256), 0, st, d_ell_idx,
+                       d_ell_val, n, r, dV, ldv, d_eig, K, scale, d_vectors, ldo);
+    FLGP_TRY(check_launch("u_recover_kernel"));
+  }
+  if (d_values_out) {
+    hipLaunchKernelGGL(values_out_kernel, dim3(ceil_div(K, 256)), dim3(256), 0, st, d_eig, K, root, d_values_out);
+    FLGP_TRY(check_launch("values_out_kernel"));
+  }
+  return FLGP_OK;
+}
