@@ -1,0 +1,212 @@
+"""bench.py -- points/sec through k-NN -> Laplacian -> truncated SVD -> heat-kernel covariance.
+
+Contract (driver): ``python bench.py --gpus N --steps K --warmup W``; for N > 1 the driver
+launches it under ``torch.distributed.run`` (one rank per GPU, RCCL).  Rank 0 prints ONE
+JSON line.
+
+Workload (BASELINE.json ``configs[2]`` / ``configs[3]``): synthetic 16-component Gaussian
+mixture, n = 1e6 points, d = 16, s = 5000 anchors (seeded random rows, 1-NN cluster counts),
+r = 10, K = 200, kernel = "lae", gl = "cluster-normalized", root = TRUE, t = 10, m = 1000
+training rows; at N GPUs the same n = 1e6 rows are sharded by row blocks (strong scaling).
+A step is one pass of the whole path over the point cloud with X and the anchors already
+resident in HBM and H (n x m) left in HBM.  Anchors and cluster sizes are inputs of the path
+(subsample_cpp is outside it), so they are prepared before the timed region.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from flgp_amd import _lib, synth  # noqa: E402
+from flgp_amd.pipeline import HeatKernelPath, HipStages, PathConfig, shard_bounds  # noqa: E402
+
+PEAK_F64_TFLOPS = 78.6     # MI355X fp64 vector = fp64 matrix dense peak (vendor figure)
+PEAK_HBM_GBS = 8000.0
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--n", type=int, default=1_000_000)
+    ap.add_argument("--d", type=int, default=16)
+    ap.add_argument("--s", type=int, default=5000)
+    ap.add_argument("--r", type=int, default=10)
+    ap.add_argument("--K", type=int, default=200)
+    ap.add_argument("--m", type=int, default=1000)
+    ap.add_argument("--t", type=float, default=10.0)
+    ap.add_argument("--cpu-rows", type=int, default=20000, help="rows of the bounded CPU-baseline sample")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    return ap.parse_args()
+
+
+def prof_query(L, name):
+    c = ctypes.c_int(0); ms = ctypes.c_double(0.0); w = ctypes.c_double(0.0)
+    L.flgp_prof_query(name.encode(), ctypes.addressof(c), ctypes.addressof(ms), ctypes.addressof(w))
+    return c.value, ms.value, w.value
+
+
+def cpu_baseline(args, X_rows, U_np, sizes_np):
+    """The oracle (kind "port") timed on this box's host cores on a bounded sample: the per-point
+    stages on the first ``cpu_rows`` rows, the s x s top-K eigen-stage at full s and K on that
+    sample's similarity matrix.  points/sec is extrapolated to the full n for the per-point
+    stages (linear in n) with the eigen-stage counted once (independent of n)."""
+    from oracle import flgp_oracle as O
+    nc = X_rows.shape[0]
+    t = {}
+    t0 = time.perf_counter()
+    kidx = O.knn(X_rows, U_np, args.r)
+    t["knn"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    ei, ev = O.lae(X_rows, U_np, args.r, knn_idx=kidx)
+    t["lae"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    zn = O.graph_laplacian(ei, ev, args.s, "cluster-normalized", sizes_np)
+    av, _ = O.scale_A(ei, zn, args.s)
+    t["laplacian"] = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    vals, Uu = O.truncated_svd(ei, av, args.s, args.K, method="svds")
+    t["truncated_svd"] = time.perf_counter() - t0
+    vec = np.asfortranarray(Uu * np.sqrt(float(nc)))
+    t0 = time.perf_counter()
+    mm = min(args.m, nc)
+    O.hk_from_spectrum(np.sqrt(vals), vec, args.K, args.t, np.arange(nc, dtype=np.int32), np.arange(mm, dtype=np.int32))
+    t["heat_kernel"] = time.perf_counter() - t0 if mm == args.m else (time.perf_counter() - t0) * args.m / mm
+    scale = args.n / float(nc)
+    # svds = Lanczos on the implicit operator: its sparse mat-vecs scale with n, the restart algebra does not;
+    # counted unscaled here, i.e. in the CPU's favour
+    total = scale * (t["knn"] + t["lae"] + t["laplacian"] + t["heat_kernel"]) + t["truncated_svd"]
+    return {
+        "value": args.n / total, "unit": "points/s", "cores": int(O.threads()), "kind": "port",
+        "sample": f"first {nc} of {args.n} rows for k-NN/LAE/Laplacian/heat-kernel (scaled x{scale:.0f}), "
+                  f"ARPACK svds at full s={args.s}, K={args.K} on that sample (counted once, unscaled)",
+        "stage_seconds_on_sample": {k: round(v, 4) for k, v in t.items()},
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with "
+                         f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP library is the only implementation of this path")
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    stages = HipStages(device)
+    path = HeatKernelPath(stages)
+    L = _lib.lib()
+
+    n, d, s = args.n, args.d, args.s
+    lo, hi = shard_bounds(n, world, rank)
+    n_loc = hi - lo
+    # ---- inputs: the local row block of the synthetic cloud, resident in HBM
+    X_np = synth.gaussian_mixture(n_loc, d, row_offset=lo)
+    X_loc = torch.from_numpy(np.ascontiguousarray(X_np.T)).to(device)       # (d, n_loc) == column-major n_loc x d
+    # anchors: a global seeded row selection; every rank contributes the rows it owns (exchange 1)
+    sel = np.sort(synth.random_anchor_rows(n, s))
+    mine = sel[(sel >= lo) & (sel < hi)] - lo
+    U_local = torch.from_numpy(np.ascontiguousarray(X_np[mine, :].T)).to(device)
+    U = path.gather_anchors(U_local)
+    assert U.shape == (d, s)
+    anchors = stages.anchor_prep(U)
+    num_class = path.cluster_sizes(X_loc, anchors)                           # 1-NN counts over all ranks
+    cfg = PathConfig(s=s, r=args.r, K=args.K, t=args.t, m=args.m)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize(device)
+
+    def step():
+        return path.run(X_loc, U, cfg, n, lo, num_class=num_class)
+
+    res = None
+    for _ in range(args.warmup):
+        res = step()
+        del res
+    barrier()
+    L.flgp_prof_reset()
+    L.flgp_prof_enable(1)
+    stage_acc = {}
+    t0 = time.perf_counter()
+    for it in range(args.steps):
+        res = step()
+        for k, v in res.stage_ms.items():
+            stage_acc[k] = stage_acc.get(k, 0.0) + v
+        if it != args.steps - 1:
+            del res
+    barrier()
+    elapsed = time.perf_counter() - t0
+    L.flgp_prof_enable(0)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed * 1e3 / args.steps
+
+    # ---- per-kernel numbers from the timed region (HIP events on the launch stream)
+    kernels = {}
+    for name in ["gemm_f64_kernel", "knn_kernel", "lae_kernel", "gram_kernel", "u_recover_kernel", "csc_build", "colsum_kernel", "jacobi_eig"]:
+        c, ms, w = prof_query(L, name)
+        if c:
+            kernels[name] = {"launches_per_step": c / args.steps, "ms_per_step": ms / args.steps,
+                             "avg_launch_ms": ms / c, "work_per_step": w / args.steps}
+    roof = None
+    if "gemm_f64_kernel" in kernels:
+        c, ms, w = prof_query(L, "gemm_f64_kernel")
+        ach = w / (ms * 1e-3) / 1e12
+        roof = {"kernel": "gemm_f64_kernel (v_mfma_f64_16x16x4_f64)", "bound": "mfma", "achieved": ach,
+                "peak": PEAK_F64_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_F64_TFLOPS, "traffic": None,
+                "launches_per_step": c / args.steps, "avg_launch_ms": ms / c,
+                "algorithmic_flops_per_launch": w / c}
+
+    out = {
+        "metric": "points/sec through k-NN->Laplacian->trunc-SVD->heat-cov, n=1e6 d=16 K=200",
+        "value": n / (ms_per_step * 1e-3), "unit": "points/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong",
+        "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": f"Gaussian-mixture n={n} d={d} s={s} r={args.r} K={args.K} m={args.m} t={args.t} "
+                               f"kernel=lae gl=cluster-normalized root=TRUE (BASELINE configs[{2 if world == 1 else 3}])",
+                   "parallelism": f"row-sharded x{world}", "rows_per_gpu": n_loc,
+                   "eig": res.eig_info},
+        "stage_ms_per_step": {k: v / args.steps for k, v in stage_acc.items()},
+        "kernels": kernels,
+    }
+    if roof:
+        out["roofline"] = roof
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        nc = min(args.cpu_rows, n_loc)
+        U_np = np.ascontiguousarray(U.t().cpu().numpy())
+        out["cpu_baseline"] = cpu_baseline(args, np.asfortranarray(X_np[:nc]), np.asfortranarray(U_np),
+                                           num_class.cpu().numpy())
+    if rank == 0:
+        if args.verbose:
+            print(json.dumps(out, indent=1), file=sys.stderr)
+        print(json.dumps(out))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -25,6 +25,10 @@ _SIGNATURES = {
     "flgp_set_device": (c_int, [c_int]),
     "flgp_parse_gl": (c_int, [c_char_p]),
     "flgp_set_tuning": (c_int, [c_char_p, c_int]),
+    "flgp_prof_enable": (None, [c_int]),
+    "flgp_prof_reset": (None, []),
+    "flgp_prof_query": (c_int, [c_char_p, P, P, P]),
+    "flgp_prof_names": (c_int, [P, c_int]),
     # host-pointer entry points
     "flgp_knn": (c_int, [P, c_int, c_int, P, c_int, c_int, c_char_p, P, P]),
     "flgp_v_to_z": (c_int, [P, c_int, P]),

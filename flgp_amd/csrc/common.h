@@ -11,6 +11,15 @@ namespace flgp {
 void set_error(const char *fmt, ...);
 int tuning(const char *key, int dflt);
 
+// optional per-launch HIP-event timing (core.hip); work = algorithmic flops or bytes of the launch
+int prof_begin(const char *name, hipStream_t st, double work);
+void prof_end(int idx, hipStream_t st);
+struct ProfScope {
+  int idx; hipStream_t st;
+  ProfScope(const char *name, hipStream_t s, double work) : idx(prof_begin(name, s, work)), st(s) {}
+  ~ProfScope() { prof_end(idx, st); }
+};
+
 inline int hip_fail(hipError_t e, const char *what, const char *file, int line) {
   set_error("HIP error %s (%d) in %s at %s:%d", hipGetErrorString(e), (int)e, what, file, line);
   return FLGP_ERR_HIP;

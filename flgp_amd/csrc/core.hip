@@ -3,6 +3,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <vector>
 
 namespace flgp {
 
@@ -23,9 +24,78 @@ int tuning(const char *key, int dflt) {
   return it == g_tune.end() ? dflt : it->second;
 }
 
+// ---- per-kernel HIP-event timing (off by default; bench.py switches it on) ----
+struct ProfRec { int name_id; hipEvent_t e0, e1; double work; };
+static std::mutex g_prof_mu;
+static bool g_prof_on = false;
+static std::vector<std::string> g_prof_names;
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<hipEvent_t> g_prof_pool;
+
+static hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) { hipEvent_t e = g_prof_pool.back(); g_prof_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+int prof_begin(const char *name, hipStream_t st, double work) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_prof_on) return -1;
+  int id = -1;
+  for (size_t i = 0; i < g_prof_names.size(); ++i) if (g_prof_names[i] == name) { id = (int)i; break; }
+  if (id < 0) { g_prof_names.push_back(name); id = (int)g_prof_names.size() - 1; }
+  ProfRec r{id, prof_event(), prof_event(), work};
+  (void)hipEventRecord(r.e0, st);
+  g_prof_recs.push_back(r);
+  return (int)g_prof_recs.size() - 1;
+}
+
+void prof_end(int idx, hipStream_t st) {
+  if (idx < 0) return;
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (idx < (int)g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[idx].e1, st);
+}
+
 }  // namespace flgp
 
 using namespace flgp;
+
+extern "C" void flgp_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  g_prof_on = on != 0;
+}
+
+extern "C" void flgp_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  for (auto &r : g_prof_recs) { g_prof_pool.push_back(r.e0); g_prof_pool.push_back(r.e1); }
+  g_prof_recs.clear();
+}
+
+// sums over all recorded launches of `name` (call after the stream is synchronised)
+extern "C" int flgp_prof_query(const char *name, int *count, double *ms, double *work) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  int c = 0; double t = 0.0, w = 0.0;
+  for (auto &r : g_prof_recs) {
+    if (g_prof_names[r.name_id] != name) continue;
+    float e = 0.f;
+    if (hipEventElapsedTime(&e, r.e0, r.e1) != hipSuccess) continue;
+    ++c; t += e; w += r.work;
+  }
+  if (count) *count = c;
+  if (ms) *ms = t;
+  if (work) *work = w;
+  return FLGP_OK;
+}
+
+// names seen so far, '\n'-separated, into buf
+extern "C" int flgp_prof_names(char *buf, int buflen) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  std::string all;
+  for (auto &n : g_prof_names) { all += n; all += '\n'; }
+  if (buf && buflen > 0) { strncpy(buf, all.c_str(), buflen - 1); buf[buflen - 1] = 0; }
+  return (int)all.size();
+}
 
 extern "C" const char *flgp_last_error(void) { return g_err; }
 extern "C" const char *flgp_version(void) { return "flgp-hip 0.1 (gfx950)"; }

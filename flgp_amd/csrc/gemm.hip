@@ -212,7 +212,10 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
   nsplit = ceil_div(Kd > 0 ? Kd : 1, klen);
   g.ksplit_len = klen;
   g.part = work;
-  hipLaunchKernelGGL(gemm_f64_kernel, dim3(ntiles, 1, nsplit), dim3(256), 0, st, g);
+  {
+    ProfScope ps("gemm_f64_kernel", st, 2.0 * (double)M * (double)N * (double)Kd);
+    hipLaunchKernelGGL(gemm_f64_kernel, dim3(ntiles, 1, nsplit), dim3(256), 0, st, g);
+  }
   FLGP_TRY(check_launch("gemm_f64_kernel"));
   if (nsplit > 1) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div((long)g.M * g.N, 256)), dim3(256), 0, st, g, nsplit);

@@ -199,6 +199,7 @@ template <int DP, int RCAP, int P, int A, int KS, int QC>
 static int launch_knn(hipStream_t st, const double *dX, int n, int ldx, int d, const double *dUt,
                       const double *duu, int s, int r, int *d_idx, double *d_dist, int ldo) {
   const int grid = ceil_div(n, 256 * P);
+  ProfScope ps("knn_kernel", st, 2.0 * (double)n * (double)s * (double)d);
   hipLaunchKernelGGL((knn_kernel<DP, RCAP, P, A, KS, QC>), dim3(grid), dim3(256), 0, st, dX, n, ldx, d,
                      dUt, duu, s, r, d_idx, d_dist, ldo);
   return check_launch("knn_kernel");

@@ -275,6 +275,7 @@ static int launch_lae(hipStream_t st, const double *dX, int n, int ldx, int d, c
   const size_t per_thread = sizeof(double) * ((size_t)r * d + (GREG ? 0 : (size_t)r * r));
   const size_t lds_full = per_thread * 64;
   const int grid = ceil_div(n, 64);
+  ProfScope ps("lae_kernel", st, 8.0 * (double)n * r);
   if (lds_full <= 160 * 1024) {
     auto kern = lae_kernel<R, GREG, true>;
     if (lds_full > 48 * 1024)

@@ -103,16 +103,24 @@ __global__ __launch_bounds__(64) void csc_scatter_kernel(const int *__restrict__
   }
 }
 
-// colsum[j] = sum over the column's entries in ascending row order (one lane per column,
-// strictly sequential adds from 0.0: the oracle's / the reference's order)
-__global__ void colsum_kernel(const double *__restrict__ val, const int *__restrict__ colptr,
-                              const int *__restrict__ pos, int s, double *__restrict__ colsum) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+// colsum[j] = sum over the column's entries in ascending row order, strictly sequential adds from
+// 0.0 (the oracle's / the reference's order).  One wave per column: the 64 lanes fetch the next 64
+// entries in parallel (that is where the time goes: two dependent gathers per entry), then the
+// values are added one after the other in entry order.
+__global__ __launch_bounds__(64) void colsum_kernel(const double *__restrict__ val, const int *__restrict__ colptr,
+                                                    const int *__restrict__ pos, int s, double *__restrict__ colsum) {
+  const int j = blockIdx.x;
   if (j >= s) return;
+  const int lane = threadIdx.x;
+  const int p0 = colptr[j], p1 = colptr[j + 1];
   double acc = 0.0;
-  const int p1 = colptr[j + 1];
-  for (int p = colptr[j]; p < p1; ++p) acc += val[pos[p]];
-  colsum[j] = acc;
+  for (int pb = p0; pb < p1; pb += 64) {
+    const int p = pb + lane;
+    const double v = (p < p1) ? val[pos[p]] : 0.0;
+    const int cnt = (p1 - pb < 64) ? p1 - pb : 64;
+    for (int l = 0; l < cnt; ++l) acc += __shfl(v, l, 64);
+  }
+  if (lane == 0) colsum[j] = acc;
 }
 
 __global__ void col_scale_kernel(const int *__restrict__ ell_idx, double *__restrict__ val, long nnz,
@@ -265,6 +273,7 @@ extern "C" int flgp_dev_csc_build(void *stream, const int *d_ell_idx, int n, int
     FLGP_HIP(hipFuncSetAttribute((const void *)csc_hist_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     FLGP_HIP(hipFuncSetAttribute((const void *)csc_scatter_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   }
+  ProfScope ps("csc_build", st, 12.0 * (double)nnz);
   hipLaunchKernelGGL(csc_hist_kernel, dim3(p.nchunks), dim3(256), lds, st, d_ell_idx, nnz, s, p.chunk, hist);
   FLGP_TRY(check_launch("csc_hist_kernel"));
   hipLaunchKernelGGL(csc_colscan_kernel, dim3(ceil_div(s, 256)), dim3(256), 0, st, hist, p.nchunks, s, tot);
@@ -278,7 +287,8 @@ extern "C" int flgp_dev_csc_build(void *stream, const int *d_ell_idx, int n, int
 
 extern "C" int flgp_dev_colsum(void *stream, const double *d_ell_val, const int *d_colptr, const int *d_pos,
                                int s, double *d_colsum) {
-  hipLaunchKernelGGL(colsum_kernel, dim3(ceil_div(s, 64)), dim3(64), 0, (hipStream_t)stream, d_ell_val, d_colptr,
+  ProfScope ps("colsum_kernel", (hipStream_t)stream, 0.0);
+  hipLaunchKernelGGL(colsum_kernel, dim3(s), dim3(64), 0, (hipStream_t)stream, d_ell_val, d_colptr,
                      d_pos, s, d_colsum);
   return check_launch("colsum_kernel");
 }
@@ -308,6 +318,7 @@ extern "C" int flgp_dev_gram(void *stream, const int *d_ell_idx, const double *d
   const size_t lds = sizeof(double) * (size_t)s;
   if (lds > 48 * 1024)
     FLGP_HIP(hipFuncSetAttribute((const void *)gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  ProfScope ps("gram_kernel", (hipStream_t)stream, 12.0 * (double)n * r + 8.0 * (double)s * s);
   hipLaunchKernelGGL(gram_kernel, dim3(s), dim3(64), lds, (hipStream_t)stream, d_ell_idx, d_ell_val, s, r, d_colptr,
                      d_pos, dG, ldg);
   return check_launch("gram_kernel");
@@ -320,6 +331,7 @@ extern "C" int flgp_dev_u_recover(void *stream, const int *d_ell_idx, const doub
   hipStream_t st = (hipStream_t)stream;
   FLGP_REQUIRE(r >= 1 && r <= FLGP_RMAX && K >= 1 && ldo >= n, "u_recover: bad shape");
   if (n > 0) {
+    ProfScope ps("u_recover_kernel", st, 12.0 * (double)n * r + 8.0 * (double)s * K + 8.0 * (double)n * K);
     hipLaunchKernelGGL(u_recover_kernel, dim3(ceil_div(n, 256), ceil_div(K, 8)), dim3(256), 0, st, d_ell_idx,
                        d_ell_val, n, r, dV, ldv, d_eig, K, scale, d_vectors, ldo);
     FLGP_TRY(check_launch("u_recover_kernel"));

@@ -52,7 +52,7 @@ def main():
     print("== spectrum", flush=True)
     Zg = api.cross_similarity_lae_cpp(X, U, r, "cluster-normalized")
     eo, vo = O.cross_similarity(X, U, r, gl="cluster-normalized")
-    for Kt, root in [(K, True), (-1, False)]:
+    for Kt, root in ([(K, True), (-1, False)] if s <= 1000 else [(K, True)]):
         t0 = time.time()
         ep = api.spectrum_from_Z_cpp(Zg, Kt, root)
         t1 = time.time()
