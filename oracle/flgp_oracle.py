@@ -227,7 +227,7 @@ def truncated_svd(eidx, aval, s, K, method="auto", seed=0):
     if method == "svds":
         from scipy.sparse.linalg import svds
         A = ell_to_csr(eidx, aval, s).tocsc()
-        ncv = min(s, max(2 * K + 1, 20))
+        ncv = min(min(n, s) - 1, max(2 * K + 1, 20))  # ARPACK needs k < ncv < min(A.shape)
         v0 = np.random.default_rng(seed).standard_normal(min(n, s))
         Uu, sv, _ = svds(A, k=K, ncv=ncv, tol=1e-10, which="LM", v0=v0, maxiter=1000 * s,
                          return_singular_vectors="u")

@@ -1,0 +1,348 @@
+"""GPU (-m gpu): the parity tests proper.  Everything goes through the C ABI of libflgp_hip.so
+(host entry points via flgp_amd.api, device entry points via flgp_amd.pipeline / ctypes) and is
+checked against the CPU oracle on the same seeded inputs, against the committed fixtures, and --
+at BASELINE.json's full size -- through size-independent properties.
+
+Bars (north_star): neighbour indices bit-exact; LAE weights, Laplacian scalings, column sums and
+the Gram matrix bit-exact as well (same operation order as the oracle); exp()-dependent values to
+4 ulp; eigenvalues to 1e-10 relative and covariance entries to 1e-8 relative to max|H| (the
+stated tolerance: "eigenpairs to 1e-8 rel")."""
+import ctypes
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import make_case
+from flgp_amd import _lib, api, synth
+from flgp_amd.pipeline import HeatKernelPath, HipStages, PathConfig
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+H_RTOL = 1e-8          # covariance entries, relative to max |H|
+EIG_RTOL = 1e-10       # eigenvalues, relative
+
+
+@pytest.fixture(scope="module")
+def stages():
+    assert torch.cuda.is_available(), "the -m gpu tests need an MI355X"
+    return HipStages("cuda:0")
+
+
+def cm(a, dev="cuda:0", dtype=torch.float64):
+    """(n x k) array -> column-major device tensor of shape (k, n)."""
+    return torch.from_numpy(np.ascontiguousarray(np.asarray(a).T)).to(dtype).to(dev)
+
+
+def to_np_cm(t):
+    return np.asfortranarray(t.cpu().numpy().T)
+
+
+# ------------------------------------------------------------------------------ k-NN (k1+k2)
+@pytest.mark.parametrize("n,d,s,r", [
+    (1000, 2, 150, 3), (777, 16, 333, 10), (513, 3, 128, 1), (300, 64, 140, 5), (200, 17, 50, 20),
+    (100, 1, 10, 10), (5, 2, 2, 2), (4097, 16, 1025, 16), (256, 8, 200, 32)])
+def test_knn_bit_exact(oracle, n, d, s, r):
+    X, U0, _ = make_case(n, d, s, r, seed=1000 + n + d, with_sizes=False)
+    res = api.KNN_cpp(X, U0, r, output=True)
+    oi, od = oracle.knn(X, U0, r, output=True)
+    np.testing.assert_array_equal(res["ind_knn"], oi)
+    order = np.argsort(oi, axis=1, kind="stable")          # distances_sp is CSR: columns ascending per row
+    sp = res["distances_sp"]
+    np.testing.assert_array_equal(sp.indices.reshape(n, r), np.take_along_axis(oi, order, axis=1))
+    np.testing.assert_array_equal(sp.data.reshape(n, r), np.take_along_axis(od, order, axis=1))
+    np.testing.assert_array_equal(api.KNN_cpp(X, U0, r)["ind_knn"], oi)   # output=FALSE path
+
+
+def test_knn_single_point(oracle):
+    rng = np.random.default_rng(4)
+    X = rng.normal(size=(1, 16)); U = rng.normal(size=(300, 16))
+    np.testing.assert_array_equal(api.KNN_cpp(X, U, 10)["ind_knn"], oracle.knn(X, U, 10))
+
+
+def test_knn_ties_and_duplicates(oracle):
+    # integer lattice with many exactly equal distances and duplicated anchors: lower index wins
+    g = np.arange(-3, 4, dtype=float)
+    U = np.array([[a, b] for a in g for b in g] + [[0.0, 0.0], [1.0, 0.0]])
+    X = np.array([[0.0, 0.0], [0.5, 0.5], [3.0, -3.0], [-1.0, 2.0]])
+    for r in (1, 4, 9, 16):
+        np.testing.assert_array_equal(api.KNN_cpp(X, U, r)["ind_knn"], oracle.knn(X, U, r))
+
+
+def test_knn_errors():
+    X = np.zeros((4, 2)); U = np.zeros((3, 2))
+    with pytest.raises(api.FlgpError) as e:
+        api.KNN_cpp(X, U, 4)          # r > s: undefined behaviour in the reference, an error here
+    assert e.value.code == -1
+    with pytest.raises(api.FlgpError) as e:
+        api.KNN_cpp(np.zeros((4, 65)), np.zeros((3, 65)), 2)
+    assert e.value.code == -1 and "<= 64" in e.value.message
+
+
+# ------------------------------------------------------------------------------ LAE (k3+k4)
+def test_v_to_z(oracle):
+    ka = np.load(os.path.join(GOLDEN, "known_answers.npz"))
+    for v, ln, z in zip(ka["v_to_z_in"], ka["v_to_z_len"], ka["v_to_z_out"]):
+        np.testing.assert_allclose(api.v_to_z_cpp(v[:ln]).ravel(), z[:ln], rtol=0, atol=1e-15)
+    rng = np.random.default_rng(3)
+    for r in (1, 2, 5, 10, 17, 32):
+        v = rng.normal(size=r) * 3
+        np.testing.assert_array_equal(api.v_to_z_cpp(v).ravel(), oracle.v_to_z(v))
+
+
+@pytest.mark.parametrize("r,d", [(1, 2), (2, 2), (3, 2), (5, 3), (8, 16), (10, 16), (12, 4), (16, 3), (20, 2), (10, 64)])
+def test_lae_bit_exact(oracle, r, d):
+    n, s = 500, 64
+    X, U0, _ = make_case(n, d, s, r, seed=31 * r + d, with_sizes=False)
+    Z = api.LAE_cpp(X, U0, r)
+    ei, ev = oracle.lae(X, U0, r)
+    np.testing.assert_array_equal(Z.indptr, np.arange(0, n * r + 1, r))
+    np.testing.assert_array_equal(Z.indices.reshape(n, r), ei)
+    np.testing.assert_array_equal(Z.data.reshape(n, r), ev)      # bit for bit
+    assert (ev >= 0).all() and np.abs(ev.sum(1) - 1).max() < 1e-13
+
+
+def test_lae_slow_converging_points(oracle):
+    # d = 2, r = 3 is the regime where a fraction of the points needs many iterations
+    # (mean 23, p99 81, some hit the T = 100 cap)
+    X, _ = synth.torus(4800)
+    U0 = synth.anchors_from_rows(X, synth.random_anchor_rows(4800, 600))
+    ei, ev, it = oracle.lae(X, U0, 3, return_iters=True)
+    assert it.max() >= 50
+    Z = api.LAE_cpp(X, U0, 3)
+    np.testing.assert_array_equal(Z.data.reshape(-1, 3), ev)
+
+
+def test_local_anchor_embedding_point(oracle):
+    rng = np.random.default_rng(9)
+    for r, d in [(3, 2), (10, 16), (5, 7)]:
+        U = rng.normal(size=(r, d)); x = U.mean(0) + 0.1 * rng.normal(size=d)
+        np.testing.assert_array_equal(api.local_anchor_embedding_cpp(x, U).ravel(), oracle.local_anchor_embedding(x, U))
+
+
+# ------------------------------------------------------------------------------ Laplacian (k5)
+@pytest.mark.parametrize("gl", ["rw", "normalized", "cluster-normalized"])
+@pytest.mark.parametrize("n,d,s,r", [(900, 3, 80, 5), (2500, 16, 300, 10)])
+def test_cross_similarity_lae_bit_exact(oracle, gl, n, d, s, r):
+    X, U0, U = make_case(n, d, s, r, seed=n + s)
+    Z = api.cross_similarity_lae_cpp(X, U, r, gl)
+    ei, zn = oracle.cross_similarity(X, U, r, gl=gl)
+    np.testing.assert_array_equal(Z.indices.reshape(n, r), ei)
+    np.testing.assert_array_equal(Z.data.reshape(n, r), zn)
+    # graphLaplacian_cpp on its own, fed with the un-normalised LAE matrix
+    Zl = api.LAE_cpp(X, U0, r)
+    np.testing.assert_array_equal(api.graphLaplacian_cpp(Zl, gl, U[:, d]).data.reshape(n, r), zn)
+
+
+def test_cross_similarity_se(oracle):
+    n, d, s, r = 1200, 3, 90, 6
+    X, U0, U = make_case(n, d, s, r, seed=5)
+    Z = api.cross_similarity_se_cpp(X, U, r, "cluster-normalized", 0.5)
+    ei, zn = oracle.cross_similarity(X, U, r, gl="cluster-normalized", kernel="se", epsilon=0.5)
+    np.testing.assert_array_equal(Z.indices.reshape(n, r), ei)
+    np.testing.assert_allclose(Z.data.reshape(n, r), zn, rtol=1e-14, atol=0)   # exp() differs by a few ulp
+
+
+def test_cluster_normalized_needs_sizes():
+    X, U0, U = make_case(100, 2, 10, 3, seed=1)
+    with pytest.raises(api.FlgpError) as e:
+        api.cross_similarity_lae_cpp(X, U0, 3, "cluster-normalized")   # the reference reads out of bounds here
+    assert e.value.code == -1
+
+
+# ------------------------------------------------------------------------------ device stages
+def test_csc_colsum_gram_bit_exact(oracle, stages):
+    n, d, s, r = 3000, 3, 257, 7
+    X, U0, U = make_case(n, d, s, r, seed=77)
+    ei, zn = oracle.cross_similarity(X, U, r, gl="normalized")
+    d_ei = torch.from_numpy(ei).cuda(); d_ev = torch.from_numpy(zn).cuda()
+    csc = stages.csc(d_ei, s)
+    colptr = csc["colptr"].cpu().numpy(); pos = csc["pos"].cpu().numpy()
+    counts = np.bincount(ei.ravel(), minlength=s)
+    np.testing.assert_array_equal(np.diff(colptr), counts)
+    for j in (0, 1, s // 2, s - 1):
+        seg = pos[colptr[j]:colptr[j + 1]]
+        assert (np.diff(seg) > 0).all() and (ei.ravel()[seg] == j).all()   # stable: rows ascending
+    np.testing.assert_array_equal(stages.colsum(d_ev, csc).cpu().numpy(), oracle.colsum(ei, zn, s))
+    av, _ = oracle.scale_A(ei, zn, s)
+    c = stages.colsum(d_ev, csc)
+    stages.col_scale(d_ei, d_ev, c, None, 1)
+    np.testing.assert_array_equal(d_ev.cpu().numpy(), av)
+    G = stages.gram(d_ei, d_ev, csc).cpu().numpy()
+    np.testing.assert_array_equal(G, oracle.gram(ei, av, s))
+    np.testing.assert_array_equal(G, G.T)
+
+
+@pytest.mark.parametrize("M,N,Kd", [(128, 128, 16), (130, 257, 33), (1, 1, 1), (500, 40, 200), (64, 64, 5000), (300, 300, 7)])
+def test_gemm_f64(stages, M, N, Kd):
+    rng = np.random.default_rng(M + N + Kd)
+    A = rng.normal(size=(M, Kd)); B = rng.normal(size=(Kd, N)); E = rng.normal(size=(M, N))
+    ref = 0.75 * (A @ B) - 1.25 * E
+    L = stages.L
+    st = torch.cuda.current_stream().cuda_stream
+    work = torch.empty(1 << 22, dtype=torch.float64, device="cuda")
+    def dev(a, colmajor):   # bytes of a column-major (or row-major) copy of `a` on the device
+        return torch.from_numpy(np.ascontiguousarray(a.T if colmajor else a)).cuda()
+
+    for a_cm in (True, False):
+        for b_cm in (True, False):
+            for c_cm in (True, False):
+                dA, dB, dE = dev(A, a_cm), dev(B, b_cm), dev(E, c_cm)
+                dC = torch.empty_like(dE)
+                a_s = (1, M) if a_cm else (Kd, 1)      # (i stride, k stride)
+                b_s = (1, Kd) if b_cm else (N, 1)      # (k stride, j stride)
+                c_s = (1, M) if c_cm else (N, 1)       # (i stride, j stride)
+                for use_work in (False, True):
+                    _lib.check(L.flgp_dev_gemm(st, M, N, Kd, 0.75, dA.data_ptr(), a_s[0], a_s[1], dB.data_ptr(), b_s[0], b_s[1],
+                                               -1.25, dE.data_ptr(), c_s[0], c_s[1], dC.data_ptr(), c_s[0], c_s[1],
+                                               work.data_ptr() if use_work else None, work.numel() if use_work else 0))
+                    got = dC.cpu().numpy()
+                    got = got.T if c_cm else got
+                    np.testing.assert_allclose(got, ref, rtol=0, atol=1e-11 * max(1.0, np.sqrt(Kd)))
+
+
+@pytest.mark.parametrize("s,K", [(60, 60), (200, 30), (300, 300), (900, 100), (2000, 100)])
+def test_eig_topk(stages, s, K):
+    rng = np.random.default_rng(s + K)
+    # PSD with a repeated top eigenvalue (three copies of 1) and a decaying tail, as the path produces
+    lam = np.concatenate([[1.0, 1.0, 1.0 - 1e-10], np.sort(rng.uniform(0.0, 0.97, s - 3))[::-1]])
+    Qr, _ = np.linalg.qr(rng.normal(size=(s, s)))
+    G = (Qr * lam) @ Qr.T
+    G = 0.5 * (G + G.T)
+    eig, V, info = stages.eig_topk(torch.from_numpy(G).cuda(), K)
+    eig = eig.cpu().numpy(); V = to_np_cm(V)
+    w = np.linalg.eigvalsh(G)[::-1][:K]
+    np.testing.assert_allclose(eig, w, rtol=EIG_RTOL, atol=1e-13)
+    np.testing.assert_allclose(V.T @ V, np.eye(K), atol=1e-10)
+    assert np.abs(G @ V - V * eig).max() < 1e-9                       # eigenpair residuals
+    # the invariant subspace agrees with LAPACK's (individual vectors inside clusters are not unique)
+    Vr = np.linalg.eigh(G)[1][:, ::-1][:, :K]
+    if K < s and w[K - 1] - np.linalg.eigvalsh(G)[::-1][K] > 1e-6:
+        assert np.linalg.norm(Vr - V @ (V.T @ Vr)) < 1e-7
+
+
+# ------------------------------------------------------------------------------ spectrum + heat kernel
+@pytest.mark.parametrize("n,d,s,r,K,root,gl", [
+    (1500, 3, 120, 4, 20, True, "cluster-normalized"),
+    (1500, 3, 120, 4, -1, False, "rw"),                 # K == s: the dense (BDCSVD) branch
+    (4000, 16, 700, 10, 50, True, "normalized"),        # the block eigensolver branch
+])
+def test_spectrum_and_heat_kernel(oracle, n, d, s, r, K, root, gl):
+    X, U0, U = make_case(n, d, s, r, seed=n + s + r)
+    Z = api.cross_similarity_lae_cpp(X, U, r, gl)
+    ei, zn = oracle.cross_similarity(X, U, r, gl=gl)
+    ep = api.spectrum_from_Z_cpp(Z, K, root)
+    ovals, ovec = oracle.spectrum_from_Z(ei, zn, s, K, root=root)
+    Kk = ovals.size
+    np.testing.assert_allclose(ep.values, ovals, rtol=EIG_RTOL, atol=1e-12)
+    np.testing.assert_allclose(ep.vectors.T @ ep.vectors / n, np.eye(Kk), atol=1e-9)
+    idx0 = np.arange(n, dtype=np.int32); idx1 = np.arange(64, dtype=np.int32)
+    Kh = min(Kk, 100)          # the bottom of a full spectrum is not unique at sigma ~ 0
+    H = api.HK_from_spectrum_cpp(ep, Kh, 2.5, idx0, idx1)
+    Ho = oracle.hk_from_spectrum(ovals, ovec, Kh, 2.5, idx0, idx1)
+    assert np.abs(H - Ho).max() <= H_RTOL * np.abs(Ho).max()
+    # the contraction kernel on its own: same spectrum in, oracle contraction as the checker
+    Hs = oracle.hk_from_spectrum(ep.values, ep.vectors, Kh, 2.5, idx0, idx1)
+    assert np.abs(H - Hs).max() <= 1e-12 * np.abs(Hs).max()
+
+
+def test_hk_gather_and_properties(oracle):
+    rng = np.random.default_rng(2)
+    n, K = 700, 37
+    vec = np.asfortranarray(rng.normal(size=(n, K)))
+    vals = np.sort(rng.uniform(0.1, 1.0, K))[::-1].copy()
+    ep = api.EigenPair(vals, vec)
+    idx0 = rng.permutation(n)[:300].astype(np.int32); idx1 = np.array([5, 699, 0, 5, 17], dtype=np.int32)
+    H = api.HK_from_spectrum_cpp(ep, K, 1.3, idx0, idx1)              # general mat_indexing gather
+    np.testing.assert_allclose(H, oracle.hk_from_spectrum(vals, vec, K, 1.3, idx0, idx1), rtol=0, atol=1e-12)
+    full = np.arange(n, dtype=np.int32)
+    H0 = api.HK_from_spectrum_cpp(ep, K, 0.0, full, full)
+    np.testing.assert_allclose(H0, vec @ vec.T, atol=1e-11)           # H(t = 0) = V V^T
+    Ht = api.HK_from_spectrum_cpp(ep, 10, 2.0, full, full)            # K smaller than stored
+    np.testing.assert_allclose(Ht, Ht.T, atol=1e-12)
+    assert np.linalg.eigvalsh(Ht).min() > -1e-10
+    with pytest.raises(api.FlgpError):
+        api.HK_from_spectrum_cpp(ep, K, 1.0, np.array([n], dtype=np.int32), idx1)
+
+
+@pytest.mark.parametrize("path", sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if "known" not in p))
+def test_golden_fixtures_through_the_abi(path):
+    g = np.load(path)
+    X, U = g["X"], g["U"]
+    d = X.shape[1]; s = U.shape[0]; r = int(g["r"]); K = int(g["K"]); t = float(g["t"]); m = int(g["m"])
+    gl = str(g["gl"]); root = bool(g["root"])
+    U0 = np.asfortranarray(U[:, :d])
+    res = api.KNN_cpp(X, U0, r)
+    np.testing.assert_array_equal(res["ind_knn"], g["knn_idx"])
+    Zl = api.LAE_cpp(X, U0, r)
+    np.testing.assert_array_equal(Zl.indices.reshape(-1, r), g["ell_idx"])
+    np.testing.assert_array_equal(Zl.data.reshape(-1, r), g["lae_val"])
+    Z = api.cross_similarity_lae_cpp(X, U, r, gl)
+    np.testing.assert_array_equal(Z.data.reshape(-1, r), g["z_val"])
+    H = api.heat_kernel_covariance_cpp(X[:m], X[m:], s, r, t, K, dict(kernel="lae", gl=gl, root=root), 1, 0.1, U=U)
+    assert H.shape == g["H"].shape
+    assert np.abs(H - g["H"]).max() <= H_RTOL * np.abs(g["H"]).max()
+
+
+def test_end_to_end_c1_like(oracle):
+    """BASELINE configs[0] shape (README torus: n=4800 d=2 s=600 r=3 K=100 m=100) end to end."""
+    X, _ = synth.torus(4800)
+    rows = synth.random_anchor_rows(4800, 600)
+    U0 = synth.anchors_from_rows(X, rows)
+    sizes = np.bincount(oracle.knn(X, U0, 1)[:, 0], minlength=600).astype(float)
+    U = np.asfortranarray(np.hstack([U0, sizes[:, None]]))
+    H = api.heat_kernel_covariance_rcpp(X[:100], X[100:], 600, 3, 10.0, K=100, U=U)
+    Ho = oracle.heat_kernel_covariance(X[:100], X[100:], U, 3, 10.0, K=100)
+    assert H.shape == (4800, 100)
+    assert np.abs(H - Ho).max() <= H_RTOL * np.abs(Ho).max()
+    em = api.lae_eigenmap(X, 600, r=3, ndim=4, U=U)
+    vals, _ = oracle.heat_kernel_spectrum(X, U, 3, 4, gl="cluster-normalized", root=True)
+    np.testing.assert_allclose(em["eigenvalues"], 1 - vals, rtol=0, atol=1e-10)
+
+
+def test_pipeline_matches_host_entry_points(oracle, stages):
+    n, d, s, r, K, m, t = 3000, 16, 300, 10, 40, 128, 6.0
+    X, U0, U = make_case(n, d, s, r, seed=2024)
+    path = HeatKernelPath(stages)
+    res = path.run(cm(X), cm(U0), PathConfig(s=s, r=r, K=K, t=t, m=m), n, 0, num_class=torch.from_numpy(U[:, d].copy()).cuda(), keep=True)
+    H = api.heat_kernel_covariance_rcpp(X[:m], X[m:], s, r, t, K=K, U=U)
+    Hp = to_np_cm(res.H)
+    assert np.abs(Hp - H).max() <= 1e-12 * np.abs(H).max()
+    np.testing.assert_array_equal(to_np_cm(res.knn_idx), oracle.knn(X, U0, r))
+
+
+# ------------------------------------------------------------------------------ full size (BASELINE configs[2])
+def test_full_size_properties(oracle, stages):
+    """n = 1e6, d = 16, s = 5000, r = 10, K = 200, m = 1000 -- one pass, checked through
+    size-independent properties plus an oracle spot check of the bit-exact stages."""
+    n, d, s, r, K, m, t = 1_000_000, 16, 5000, 10, 200, 1000, 10.0
+    X = synth.gaussian_mixture(n, d)
+    sel = np.sort(synth.random_anchor_rows(n, s))
+    U0 = np.asfortranarray(X[sel])
+    path = HeatKernelPath(stages)
+    dX = cm(X); dU = cm(U0)
+    sizes = path.cluster_sizes(dX, stages.anchor_prep(dU))
+    assert float(sizes.sum()) == n
+    res = path.run(dX, dU, PathConfig(s=s, r=r, K=K, t=t, m=m), n, 0, num_class=sizes, keep=True)
+    # k-NN + LAE: bit-exact against the oracle on a random sample of rows
+    rows = np.random.default_rng(0).choice(n, 3000, replace=False)
+    oi = oracle.knn(np.asfortranarray(X[rows]), U0, r)
+    np.testing.assert_array_equal(res.knn_idx[:, torch.from_numpy(rows).cuda()].cpu().numpy().T, oi)
+    assert int(res.ell_idx.min()) >= 0 and int(res.ell_idx.max()) < s
+    assert bool((res.ell_idx[:, 1:] > res.ell_idx[:, :-1]).all())            # CSR inner order, no duplicates
+    # spectrum: sigma_1 = 1, descending, V^T V = n I
+    vals = res.values.cpu().numpy()
+    assert abs(vals[0] - 1.0) < 1e-6 and (np.diff(vals) <= 1e-12).all() and vals[-1] > 0
+    VtV = (res.vectors @ res.vectors.T / n).cpu().numpy()
+    np.testing.assert_allclose(VtV, np.eye(K), atol=1e-8)
+    # H on the training block: symmetric PSD; equals V diag(w) V^T recomputed in torch fp64 on a slice
+    Htrain = res.H[:, :m].cpu().numpy()                                       # (m, m)
+    np.testing.assert_allclose(Htrain, Htrain.T, atol=1e-8 * np.abs(Htrain).max())
+    assert np.linalg.eigvalsh(0.5 * (Htrain + Htrain.T)).min() > -1e-6 * np.abs(Htrain).max()
+    w = torch.exp(-t * (1.0 - res.values))
+    sl = slice(123456, 123456 + 4096)
+    ref = (res.vectors[:, :m].T * w) @ res.vectors[:, sl]                      # (m, 4096)
+    got = res.H[:, sl]
+    assert float((got - ref).abs().max()) <= 1e-10 * float(ref.abs().max())
