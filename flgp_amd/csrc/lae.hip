@@ -79,15 +79,16 @@ __global__ __launch_bounds__(64) void lae_kernel(const double *__restrict__ X, i
                                                  const double *__restrict__ Ut, int dpad, int r_rt,
                                                  const int *__restrict__ knn_idx, int ldk,
                                                  int *__restrict__ ell_idx, double *__restrict__ ell_val,
-                                                 int *__restrict__ iters_out) {
-  constexpr int NT = 64;
+                                                 int *__restrict__ iters_out, int NT) {
+  // NT = lanes of the wave that own a point (64 unless the per-point LDS footprint forces fewer)
   constexpr int RR = LaeDims<R>::RR;
   const int r = R ? R : r_rt;
   extern __shared__ double lds[];
   const int tid = threadIdx.x;
   long i = (long)blockIdx.x * NT + tid;
-  const bool live = i < n;
-  if (!live) i = n - 1;
+  const bool live = tid < NT && i < n;
+  if (i >= n) i = n - 1;
+  if (tid >= NT) return;   // no barriers in this kernel: idle lanes may leave
 
   double *Ul = lds;                                         // [a][k][lane]
   double *Gl = lds + (UI_LDS ? (size_t)r * d * NT : 0);     // [a][b][lane] when !GREG
@@ -272,24 +273,24 @@ __global__ void se_weights_kernel(const int *__restrict__ knn_idx, const double 
 template <int R, bool GREG>
 static int launch_lae(hipStream_t st, const double *dX, int n, int ldx, int d, const double *dUt, int dpad,
                       int r, const int *d_knn, int ldk, int *d_ei, double *d_ev, int *d_iters) {
-  const size_t per_thread = sizeof(double) * ((size_t)r * d + (GREG ? 0 : (size_t)r * r));
-  const size_t lds_full = per_thread * 64;
-  const int grid = ceil_div(n, 64);
+  const size_t g_bytes = GREG ? 0 : sizeof(double) * (size_t)r * r;   // per point
+  const size_t u_bytes = sizeof(double) * (size_t)r * d;
+  const size_t budget = 150 * 1024;
   ProfScope ps("lae_kernel", st, 8.0 * (double)n * r);
-  if (lds_full <= 160 * 1024) {
-    auto kern = lae_kernel<R, GREG, true>;
-    if (lds_full > 48 * 1024)
-      FLGP_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_full));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds_full, st, dX, n, ldx, d, dUt, dpad, r, d_knn, ldk, d_ei,
-                       d_ev, d_iters);
-  } else {  // anchors too large for LDS: read them through L2 instead
-    const size_t lds_g = GREG ? 0 : sizeof(double) * (size_t)r * r * 64;
-    auto kern = lae_kernel<R, GREG, false>;
-    if (lds_g > 48 * 1024)
-      FLGP_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds_g, st, dX, n, ldx, d, dUt, dpad, r, d_knn, ldk, d_ei, d_ev,
-                       d_iters);
-  }
+  // prefer the anchors in LDS with all 64 lanes busy; give up lanes before giving up LDS residency
+  // only for the Gram block (which has nowhere else to live when r > 10)
+  bool ui_lds = (u_bytes + g_bytes) * 64 <= budget;
+  int nt = 64;
+  if (!ui_lds)
+    while (nt > 8 && g_bytes * nt > budget) nt >>= 1;
+  FLGP_REQUIRE(ui_lds || g_bytes * nt <= budget, "LAE: r=%d does not fit the LDS budget", r);
+  const size_t lds = (ui_lds ? u_bytes + g_bytes : g_bytes) * nt;
+  const int grid = ceil_div(n, nt);
+  auto kern = ui_lds ? lae_kernel<R, GREG, true> : lae_kernel<R, GREG, false>;
+  if (lds > 48 * 1024)
+    FLGP_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, st, dX, n, ldx, d, dUt, dpad, r, d_knn, ldk, d_ei, d_ev,
+                     d_iters, nt);
   return check_launch("lae_kernel");
 }
 
