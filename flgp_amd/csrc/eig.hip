@@ -77,7 +77,7 @@ __device__ __host__ inline void rr_pair(int m2, int rr, int k, int &p, int &q) {
 // one cyclic sweep of Hestenes rotations inside LDS, applied to B and accumulated into V.
 // flags[0]: number of rotations applied in this sweep (convergence when it stays 0)
 // flags[1]: "converged" latch set by the host-side protocol (kernel exits early)
-__global__ __launch_bounds__(256) void jac_round_kernel(double *__restrict__ B, double *__restrict__ V, int b,
+__global__ __launch_bounds__(1024) void jac_round_kernel(double *__restrict__ B, double *__restrict__ V, int b,
                                                         int ldb, int w, int nbc, int round, double tol,
                                                         int *__restrict__ flags, int local_sweeps) {
   extern __shared__ double sm[];
@@ -122,9 +122,18 @@ __global__ __launch_bounds__(256) void jac_round_kernel(double *__restrict__ B, 
         bool act = k < npair;
         if (act) { rr_pair(m2, rr, k, p, q); act = (q < ncol); }
         double al = 0.0, be = 0.0, ga = 0.0;
+        constexpr int RC = 8;                 // rows of the pair kept in registers between dots and rotation
+        double xr[RC], yr[RC];
+        double *bp_ = LB + (size_t)p * bp, *bq_ = LB + (size_t)q * bp;
         if (act) {
-          const double *bp_ = LB + (size_t)p * bp, *bq_ = LB + (size_t)q * bp;
-          for (int i = gl; i < b; i += gs) {
+#pragma unroll
+          for (int c = 0; c < RC; ++c) {
+            const int i = gl + c * gs;
+            xr[c] = (i < b) ? bp_[i] : 0.0;
+            yr[c] = (i < b) ? bq_[i] : 0.0;
+            al = __builtin_fma(xr[c], xr[c], al); be = __builtin_fma(yr[c], yr[c], be); ga = __builtin_fma(xr[c], yr[c], ga);
+          }
+          for (int i = gl + RC * gs; i < b; i += gs) {
             const double x = bp_[i], y = bq_[i];
             al = __builtin_fma(x, x, al); be = __builtin_fma(y, y, be); ga = __builtin_fma(x, y, ga);
           }
@@ -132,13 +141,22 @@ __global__ __launch_bounds__(256) void jac_round_kernel(double *__restrict__ B, 
         for (int off = gs >> 1; off > 0; off >>= 1) {
           al += __shfl_xor(al, off, 64); be += __shfl_xor(be, off, 64); ga += __shfl_xor(ga, off, 64);
         }
-        if (act && __builtin_fabs(ga) > tol * __builtin_sqrt(al * be) && al > 0.0 && be > 0.0) {
+        // |ga| > tol sqrt(al be), squared to stay off the sqrt unit
+        if (act && ga * ga > (tol * tol) * (al * be) && al > 0.0 && be > 0.0) {
           const double zeta = (be - al) / (2.0 * ga);
           const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (__builtin_fabs(zeta) + __builtin_sqrt(1.0 + zeta * zeta));
           const double cs = 1.0 / __builtin_sqrt(1.0 + tt * tt), sn = cs * tt;
-          double *bp_ = LB + (size_t)p * bp, *bq_ = LB + (size_t)q * bp;
           double *vp_ = LV + (size_t)p * bp, *vq_ = LV + (size_t)q * bp;
-          for (int i = gl; i < b; i += gs) {
+#pragma unroll
+          for (int c = 0; c < RC; ++c) {
+            const int i = gl + c * gs;
+            if (i < b) {
+              bp_[i] = cs * xr[c] - sn * yr[c]; bq_[i] = sn * xr[c] + cs * yr[c];
+              const double u = vp_[i], v = vq_[i];
+              vp_[i] = cs * u - sn * v; vq_[i] = sn * u + cs * v;
+            }
+          }
+          for (int i = gl + RC * gs; i < b; i += gs) {
             const double x = bp_[i], y = bq_[i];
             bp_[i] = cs * x - sn * y; bq_[i] = sn * x + cs * y;
             const double u = vp_[i], v = vq_[i];
@@ -304,7 +322,7 @@ static JacobiPlan jacobi_plan(int b) {
   p.nbc = (b + p.w - 1) / p.w;
   if (p.nbc & 1) ++p.nbc;
   if (p.nbc < 2) p.nbc = 2;
-  p.nt = 256;
+  p.nt = 1024;
   p.lds = sizeof(double) * 4 * (size_t)p.w * (b + 16);
   return p;
 }
@@ -430,7 +448,7 @@ static int jacobi_refine(hipStream_t st, const double *T, int b, int K, EigWork 
   FLGP_HIP(hipFuncSetAttribute((const void *)jac_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                150 * 1024));
   const double tol_g = 4.0 * std::sqrt((double)g) * 1.1102230246251565e-16;
-  hipLaunchKernelGGL(jac_round_kernel, dim3(1), dim3(256), lds_small, st, Bg, Vg, g, g, wg, 2, 0, tol_g, w.flags, 40);
+  hipLaunchKernelGGL(jac_round_kernel, dim3(1), dim3(1024), lds_small, st, Bg, Vg, g, g, wg, 2, 0, tol_g, w.flags, 40);
   FLGP_TRY(check_launch("jac_round_kernel(guard block)"));
   hipLaunchKernelGGL(embed_block_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, Vg, g, K, b, w.JV);
   FLGP_TRY(check_launch("embed_block_kernel"));
@@ -630,10 +648,12 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     // (a fixed small number of global sweeps alone is NOT enough, even late: the guard columns
     //  never converge, so their diagonal block of T stays dense -- measured: 2 sweeps put rmax
     //  back to 4e-2.  jacobi_refine diagonalises that block first, inside one workgroup.)
-    if (rmax_prev > 3e-3)
+    if (it < 2)         // bounds and a rough Ritz basis are all that is needed yet: loose threshold
+      FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps, -1, 1e10));
+    else if (rmax_prev > 5e-2)
       FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps, -1, 1e6));
     else
-      FLGP_TRY(jacobi_refine(st, w.T, b, K, w, lam, &sweeps, rmax_prev > 1e-6 ? 2 : 1));
+      FLGP_TRY(jacobi_refine(st, w.T, b, K, w, lam, &sweeps, rmax_prev > 3e-3 ? 3 : (rmax_prev > 1e-6 ? 2 : 1)));
     FLGP_TRY(sorted_basis(st, lam, nullptr, b, b, w, order));
     for (int j = 0; j < b; ++j) theta[j] = lam[order[j]];
     FLGP_TRY(rotate(Q, w.W, A));   // A = Ritz vectors
