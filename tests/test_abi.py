@@ -93,3 +93,19 @@ def test_product_never_imports_the_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
                 assert "flgp_oracle" not in src or f.endswith((".hip", ".h")) and "oracle/flgp_oracle.c" in src, f
+
+
+def test_r_shim_type_checks_and_registers_the_reference_symbols():
+    """The .Call shim cannot run here (no R), but it must at least type-check against the C ABI
+    header and register the reference's symbol names with the reference's arities
+    (src/RcppExports.cpp:471-499)."""
+    import subprocess
+    shim = os.path.join(ROOT, "flgp_amd", "csrc", "rshim", "flgp_rcall.c")
+    subprocess.run(["gcc", "-fsyntax-only", "-Wall", "-Wextra", "-Werror", "-Wno-cast-function-type", "-I", os.path.join(ROOT, "tests", "r_mock"),
+                    "-I", os.path.join(ROOT, "include"), shim], check=True)
+    text = open(shim).read()
+    expect = {"_FLGP_lae_eigenmap": 7, "_FLGP_heat_kernel_covariance_cpp": 9, "_FLGP_cross_similarity_lae_cpp": 4,
+              "_FLGP_subsample_cpp": 4, "_FLGP_KNN_cpp": 6, "_FLGP_LAE_cpp": 3,
+              "_FLGP_local_anchor_embedding_cpp": 2, "_FLGP_v_to_z_cpp": 1}
+    got = {m.group(1): int(m.group(2)) for m in re.finditer(r'\{"(_FLGP_\w+)",\s*\(DL_FUNC\)&\w+,\s*(\d+)\}', text)}
+    assert got == expect
