@@ -167,7 +167,7 @@ def main():
 
     # ---- per-kernel numbers from the timed region (HIP events on the launch stream)
     kernels = {}
-    for name in ["gemm_f64_kernel", "knn_kernel", "lae_kernel", "gram_kernel", "u_recover_kernel", "csc_build", "colsum_kernel", "jacobi_eig"]:
+    for name in ["gemm_f64_kernel", "knn_kernel", "lae_kernel", "gram_kernel", "u_recover_kernel", "csc_build", "colsum_kernel", "jacobi_eig", "jacobi_refine"]:
         c, ms, w = prof_query(L, name)
         if c:
             kernels[name] = {"launches_per_step": c / args.steps, "ms_per_step": ms / args.steps,

@@ -73,6 +73,14 @@ __device__ __host__ inline void rr_pair(int m2, int rr, int k, int &p, int &q) {
   if (p > q) { const int t = p; p = q; q = t; }
 }
 
+// 1/sqrt(x) to double precision: hardware estimate + two Newton steps (x > 0, normal range)
+__device__ __forceinline__ double rsqrt_nr(double x) {
+  double y = __builtin_amdgcn_rsq(x);
+  y = y * (1.5 - (0.5 * x) * (y * y));
+  y = y * (1.5 - (0.5 * x) * (y * y));
+  return y;
+}
+
 // One workgroup orthogonalises the 2w columns of block columns (I, J) against each other:
 // one cyclic sweep of Hestenes rotations inside LDS, applied to B and accumulated into V.
 // flags[0]: number of rotations applied in this sweep (convergence when it stays 0)
@@ -143,9 +151,16 @@ __global__ __launch_bounds__(1024) void jac_round_kernel(double *__restrict__ B,
         }
         // |ga| > tol sqrt(al be), squared to stay off the sqrt unit
         if (act && ga * ga > (tol * tol) * (al * be) && al > 0.0 && be > 0.0) {
-          const double zeta = (be - al) / (2.0 * ga);
-          const double tt = (zeta >= 0.0 ? 1.0 : -1.0) / (__builtin_fabs(zeta) + __builtin_sqrt(1.0 + zeta * zeta));
-          const double cs = 1.0 / __builtin_sqrt(1.0 + tt * tt), sn = cs * tt;
+          // rotation with tan(2 th) = 2 ga / (be - al), |th| <= pi/4, from two reciprocal square roots
+          // (v_rsq_f64 + two Newton steps each) instead of three IEEE divisions and two square roots:
+          //   r1 = 1/sqrt(dl^2 + 4 ga^2), cos(2th) = |dl| r1, x = (1 + cos 2th)/2, r2 = 1/sqrt(x),
+          //   c = x r2, s = sign(dl) ga r1 r2        (c^2 + s^2 = 1 to rounding)
+          const double dl = be - al;
+          const double r1 = rsqrt_nr(dl * dl + 4.0 * (ga * ga));
+          const double x2 = 0.5 + 0.5 * (__builtin_fabs(dl) * r1);
+          const double r2 = rsqrt_nr(x2);
+          const double cs = x2 * r2;
+          const double sn = (dl >= 0.0 ? ga : -ga) * (r1 * r2);
           double *vp_ = LV + (size_t)p * bp, *vq_ = LV + (size_t)q * bp;
 #pragma unroll
           for (int c = 0; c < RC; ++c) {
@@ -542,15 +557,16 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
                        w.gemm_ws_elems, 0.0, nullptr);
   };
   auto rotate = [&](const double *Xin, const double *Wm, double *out) {  // out = Xin Wm   (s x b)(b x b)
-    return gemm_launch(st, s, b, b, 1.0, Xin, 1, s, Wm, 1, b, 0.0, nullptr, 0, 0, out, 1, s, nullptr, 0, 0.0,
-                       nullptr);
+    return gemm_launch(st, s, b, b, 1.0, Xin, 1, s, Wm, 1, b, 0.0, nullptr, 0, 0, out, 1, s, w.gemm_ws,
+                       w.gemm_ws_elems, 0.0, nullptr);
   };
   // orthonormalise the columns of Yin into Qout ("SVQB" on the column-normalised block, so that
   // the widely different column norms a Chebyshev filter leaves behind do not enter the
   // conditioning of the Gram matrix); returns the condition estimate of the scaled Gram matrix
   auto small_gemm = [&](const double *Am, const double *Bm, double alpha, double beta, const double *E,
                         double *out) {  // out = alpha Am Bm + beta E   (b x b, column-major)
-    return gemm_launch(st, b, b, b, alpha, Am, 1, b, Bm, 1, b, beta, E, 1, b, out, 1, b, nullptr, 0, 0.0, nullptr);
+    return gemm_launch(st, b, b, b, alpha, Am, 1, b, Bm, 1, b, beta, E, 1, b, out, 1, b, w.gemm_ws, w.gemm_ws_elems,
+                       0.0, nullptr);
   };
   auto dist_to_identity = [&](const double *M, double *out) -> int {
     hipLaunchKernelGGL(dist_to_identity_kernel, dim3(1), dim3(1024), 0, st, M, b, w.res);
@@ -575,19 +591,23 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
       //   M = (3 I - Z Y)/2,  Y <- Y M,  Z <- M Z ;  Y -> S^1/2, Z -> S^-1/2   (|I - S| < 1)
       double *Yc = w.T, *Zc = w.JV, *Mm = w.W, *Yn = w.JB, *Zn = w.X2;
       FLGP_HIP(hipMemcpyAsync(Zc, w.Id, sizeof(double) * (size_t)b * b, hipMemcpyDeviceToDevice, st));
+      // the error contracts quadratically, e <- (3/4) e^2 + O(e^3): run the predicted number of
+      // iterations without talking to the host, then check once (|I - S|_F over-estimates e, so
+      // the prediction errs on the safe side); a block that does not contract falls through to Jacobi
+      int kmax = 2;
+      for (double e = std::min(delta, 0.95); e > 1e-17 && kmax < 40; ++kmax) e = (e < 0.5) ? 0.8 * e * e : 0.5 * e + 0.4 * e * e;
       bool ok = false;
-      double dm_prev = 1e300;
-      for (int k = 0; k < 20; ++k) {
+      for (int k = 0; k < kmax; ++k) {
         FLGP_TRY(small_gemm(Zc, Yc, -0.5, 1.5, w.Id, Mm));
-        double dm = 0.0;
-        FLGP_TRY(dist_to_identity(Mm, &dm));
-        if (!(dm < 2.0 * dm_prev) || !(dm < 1e3)) break;   // not contracting: |I - S|_2 >= 1, leave it to Jacobi
-        dm_prev = dm;
         FLGP_TRY(small_gemm(Yc, Mm, 1.0, 0.0, nullptr, Yn));
         FLGP_TRY(small_gemm(Mm, Zc, 1.0, 0.0, nullptr, Zn));
         std::swap(Yc, Yn);
         std::swap(Zc, Zn);
-        if (dm < 1e-14 * std::sqrt((double)b)) { ok = true; break; }
+      }
+      {
+        double dm = 0.0;   // the last M must be the identity to rounding
+        FLGP_TRY(dist_to_identity(Mm, &dm));
+        ok = dm < 1e-13 * std::sqrt((double)b);
       }
       if (ok) {
         // Zc may live in JV or X2; the rotation needs diag(dinv) Z in W
