@@ -200,6 +200,179 @@ __global__ __launch_bounds__(1024) void jac_round_kernel(double *__restrict__ B,
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// Block-Jacobi visit with the heavy parts on the matrix cores (b % 16 == 0, NLOC = 2w local columns).
+//
+// One workgroup (16 waves) makes the NLOC columns of block columns (I, J) mutually orthogonal:
+//   1. the B panel (b x NLOC) is staged in LDS, column-major with column stride b+2
+//      (the 16-column MFMA fragment reads then hit 16 distinct bank pairs);
+//   2. Gram block Gm = P^T P (NLOC x NLOC) by v_mfma_f64_16x16x4_f64, the b rows split over 4 waves
+//      per 16 x 16 tile and summed in a fixed order;
+//   3. two-sided cyclic Jacobi on the small Gm inside LDS, accumulating the rotations in Wm
+//      (rotation angles from Gm_pp, Gm_qq, Gm_pq: exactly the one-sided Hestenes angles);
+//   4. P <- P Wm by MFMA (each wave owns 16 panel rows: reads them all, then overwrites them),
+//      stored back; the V panel goes through the same LDS buffer and the same Wm.
+// Per visit the panels are written to LDS twice instead of once per local round (LDS stores are
+// the slow direction on CDNA4), which is what made the scalar version (jac_round_kernel) slow.
+// ------------------------------------------------------------------------------------------
+typedef double jd4 __attribute__((ext_vector_type(4)));
+
+template <int NLOC>
+__global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B, double *__restrict__ V, int b,
+                                                         int ldb, int nbc, int round, double tol,
+                                                         int *__restrict__ flags, int local_sweeps) {
+  constexpr int WB = NLOC / 2;        // block-column width
+  constexpr int NP = NLOC / 2;        // pairs per local round
+  constexpr int NT16 = NLOC / 16;     // 16-wide tiles per side
+  constexpr int TILES = NT16 * NT16;
+  constexpr int KP = 4;               // row parts of the Gram product
+  extern __shared__ double sm[];
+  __shared__ int any_rot;
+  if (flags[1]) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int I, J;
+  rr_pair(nbc, round, blockIdx.x, I, J);
+  const int cI = I * WB, cJ = J * WB;
+  if (cI >= b) return;
+  const int bp = b + 2;
+  double *P = sm;                         // [NLOC][bp]   column-major panel
+  double *Gm = P + (size_t)NLOC * bp;     // [NLOC][NLOC]
+  double *Wm = Gm + NLOC * NLOC;          // [NLOC][NLOC] row-major: Wm[k][c]
+  double *part = Wm + NLOC * NLOC;        // [KP][NLOC][NLOC]
+  auto gcol = [&](int c) { return (c < WB) ? cI + c : cJ + (c - WB); };
+
+  auto load_panel = [&](const double *M) {
+    for (int c = wave; c < NLOC; c += 16) {
+      const int gc = gcol(c);
+      for (int i = lane; i < b; i += 64) P[(size_t)c * bp + i] = (gc < b) ? M[(size_t)gc * ldb + i] : 0.0;
+    }
+  };
+  auto store_panel = [&](double *M) {
+    for (int c = wave; c < NLOC; c += 16) {
+      const int gc = gcol(c);
+      if (gc < b)
+        for (int i = lane; i < b; i += 64) M[(size_t)gc * ldb + i] = P[(size_t)c * bp + i];
+    }
+  };
+  // P <- P Wm : each wave owns row blocks of 16 rows (reads all its inputs before it writes)
+  auto apply_w = [&]() {
+    for (int rb = wave; rb < b / 16; rb += 16) {
+      const int i0 = rb * 16;
+      double bf[NLOC / 4];
+#pragma unroll
+      for (int kk = 0; kk < NLOC / 4; ++kk) bf[kk] = P[(size_t)(kk * 4 + (lane >> 4)) * bp + i0 + (lane & 15)];
+      jd4 acc[NT16];
+#pragma unroll
+      for (int tc = 0; tc < NT16; ++tc) {
+        acc[tc] = jd4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < NLOC / 4; ++kk) {
+          const double a = Wm[(kk * 4 + (lane >> 4)) * NLOC + tc * 16 + (lane & 15)];
+          acc[tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bf[kk], acc[tc], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int tc = 0; tc < NT16; ++tc)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg)
+          P[(size_t)(tc * 16 + (lane >> 4) + 4 * reg) * bp + i0 + (lane & 15)] = acc[tc][reg];
+    }
+  };
+
+  load_panel(B);
+  __syncthreads();
+  // ---- Gram block on the matrix cores
+  if (wave < TILES * KP) {
+    const int tile = wave % TILES, kp = wave / TILES;
+    const int tp = tile / NT16, tq = tile % NT16;
+    const int rows = b / KP;  // multiple of 4 because b % 16 == 0
+    jd4 acc = jd4{0.0, 0.0, 0.0, 0.0};
+    const double *pa = P + (size_t)(tp * 16 + (lane & 15)) * bp + (lane >> 4);
+    const double *pb = P + (size_t)(tq * 16 + (lane & 15)) * bp + (lane >> 4);
+    for (int i0 = kp * rows; i0 < (kp + 1) * rows; i0 += 4)
+      acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[i0], pb[i0], acc, 0, 0, 0);
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg)
+      part[(size_t)(kp * NLOC + tp * 16 + (lane >> 4) + 4 * reg) * NLOC + tq * 16 + (lane & 15)] = acc[reg];
+  }
+  __syncthreads();
+  for (int e = tid; e < NLOC * NLOC; e += 1024) {
+    double g = part[e];
+#pragma unroll
+    for (int kp = 1; kp < KP; ++kp) g += part[kp * NLOC * NLOC + e];
+    Gm[e] = g;
+    Wm[e] = (e / NLOC == e % NLOC) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  // ---- two-sided cyclic Jacobi on Gm, rotations accumulated in Wm.
+  // Per round: NP leader lanes turn (Gm_pp, Gm_qq, Gm_pq) into rotation coefficients, then every
+  // thread rebuilds ONE element of J^T Gm J and of Wm J from the old buffers into the other
+  // buffers (4 + 2 reads, no read-modify-write), so a round costs two barriers.
+  double *G2 = part;                 // the Gram partials are dead by now: reuse as the second buffers
+  double *W2 = part + NLOC * NLOC;
+  double *cc = part + 2 * NLOC * NLOC;   // per index: cos, signed sin, partner
+  double *dd = cc + NLOC;
+  int *pr = (int *)(dd + NLOC);
+  double *Gc = Gm, *Gn = G2, *Wc = Wm, *Wn = W2;
+  const double tol2 = tol * tol;
+  int rotations = 0;
+  for (int ls = 0; ls < local_sweeps; ++ls) {
+    if (tid == 0) any_rot = 0;
+    __syncthreads();
+    int rot_here = 0;
+    for (int rr = 0; rr < NLOC - 1; ++rr) {
+      if (tid < NP) {
+        int p, q;
+        rr_pair(NLOC, rr, tid, p, q);
+        const double al = Gc[p * NLOC + p], be = Gc[q * NLOC + q], ga = Gc[p * NLOC + q];
+        double cs = 1.0, sn = 0.0;
+        if (ga * ga > tol2 * (al * be) && al > 0.0 && be > 0.0) {
+          const double dl = be - al;
+          const double r1 = rsqrt_nr(dl * dl + 4.0 * (ga * ga));
+          const double x2 = 0.5 + 0.5 * (__builtin_fabs(dl) * r1);
+          const double r2 = rsqrt_nr(x2);
+          cs = x2 * r2;
+          sn = (dl >= 0.0 ? ga : -ga) * (r1 * r2);
+          ++rot_here;
+        }
+        cc[p] = cs; dd[p] = -sn; pr[p] = q;   // new_p = c old_p - s old_q
+        cc[q] = cs; dd[q] = sn;  pr[q] = p;   // new_q = s old_p + c old_q
+      }
+      __syncthreads();
+      for (int e = tid; e < NLOC * NLOC; e += 1024) {
+        const int i = e / NLOC, j = e % NLOC;
+        const int pi = pr[i], pj = pr[j];
+        const double ci = cc[i], di = dd[i], cj = cc[j], dj = dd[j];
+        Gn[e] = ci * (cj * Gc[i * NLOC + j] + dj * Gc[i * NLOC + pj]) + di * (cj * Gc[pi * NLOC + j] + dj * Gc[pi * NLOC + pj]);
+        Wn[e] = cj * Wc[i * NLOC + j] + dj * Wc[i * NLOC + pj];
+      }
+      __syncthreads();
+      double *t1 = Gc; Gc = Gn; Gn = t1;
+      double *t2 = Wc; Wc = Wn; Wn = t2;
+    }
+    rotations += rot_here;
+    if (rot_here) any_rot = 1;
+    __syncthreads();
+    if (!any_rot) break;
+    __syncthreads();
+  }
+  if (Wc != Wm) {   // an odd number of rounds ran: move the result where apply_w reads it
+    for (int e = tid; e < NLOC * NLOC; e += 1024) Wm[e] = Wc[e];
+  }
+  __syncthreads();
+  if (rotations) atomicAdd(&flags[0], rotations);
+  // ---- apply the accumulated rotation to the B panel, then to the V panel (same LDS buffer)
+  apply_w();
+  __syncthreads();
+  store_panel(B);
+  __syncthreads();
+  load_panel(V);
+  __syncthreads();
+  apply_w();
+  __syncthreads();
+  store_panel(V);
+}
+
 // keep the strictly upper triangle (i < j) of the b x b matrix C, zero the rest
 __global__ void mask_strict_upper_kernel(double *__restrict__ C, int b) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -325,10 +498,24 @@ __global__ void resid_kernel(const double *__restrict__ Z, const double *__restr
 // ------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------
-struct JacobiPlan { int w, nbc, nt; size_t lds; };
+struct JacobiPlan { int w, nbc, nt; size_t lds; int nloc; /* 32 / 16: MFMA block kernel, 0: scalar kernel */ };
+
+static size_t jac_block_lds(int b, int nloc) { return sizeof(double) * ((size_t)nloc * (b + 2) + 6 * (size_t)nloc * nloc); }
+static_assert(true, "part[] holds 4 Gram partials = 4 nloc^2 doubles; the local Jacobi reuses 2 nloc^2 + 3 nloc of them");
 
 static JacobiPlan jacobi_plan(int b) {
   JacobiPlan p;
+  p.nloc = 0;
+  if (b % 16 == 0 && b >= 32 && tuning("jacobi_scalar", 0) == 0) {
+    for (int nloc : {32, 16}) {
+      if (jac_block_lds(b, nloc) <= 150 * 1024) {
+        p.nloc = nloc; p.w = nloc / 2; p.nbc = (b + p.w - 1) / p.w;
+        if (p.nbc & 1) ++p.nbc;
+        p.nt = 1024; p.lds = jac_block_lds(b, nloc);
+        return p;
+      }
+    }
+  }
   // 2w columns of B and of V, each b+16 doubles, must fit ~150 KB of LDS
   int w = (int)((150 * 1024) / (sizeof(double) * 4 * (size_t)(b + 16)));
   int pw = 1;
@@ -396,9 +583,10 @@ static size_t eig_workspace_bytes(int s, int K) {
 static int jacobi_run(hipStream_t st, int b, EigWork &w, std::vector<double> &h_lam, int *sweeps_out,
                       int sweep_limit, double tol_scale, bool strict) {
   const JacobiPlan p = jacobi_plan(b);
+  const void *kfn = p.nloc == 32 ? (const void *)jac_block_kernel<32>
+                  : p.nloc == 16 ? (const void *)jac_block_kernel<16> : (const void *)jac_round_kernel;
   if (p.lds > 48 * 1024)
-    FLGP_HIP(hipFuncSetAttribute((const void *)jac_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)p.lds));
+    FLGP_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
   FLGP_HIP(hipMemsetAsync(w.flags, 0, sizeof(int) * 3, st));
   const bool to_convergence = sweep_limit < 0;
   const int max_sweeps = to_convergence ? 60 : sweep_limit;
@@ -408,8 +596,15 @@ static int jacobi_run(hipStream_t st, int b, EigWork &w, std::vector<double> &h_
   int h_flags[4] = {0, 0, 0, 0};
   for (int sw = 0; sw < max_sweeps; ++sw) {
     for (int round = 0; round < p.nbc - 1; ++round) {
-      hipLaunchKernelGGL(jac_round_kernel, dim3(p.nbc / 2), dim3(p.nt), p.lds, st, w.JB, w.JV, b, b, p.w, p.nbc,
-                         round, tol, w.flags, 1);
+      if (p.nloc == 32)
+        hipLaunchKernelGGL(jac_block_kernel<32>, dim3(p.nbc / 2), dim3(1024), p.lds, st, w.JB, w.JV, b, b, p.nbc, round,
+                           tol, w.flags, tuning("jacobi_local_sweeps", 1));
+      else if (p.nloc == 16)
+        hipLaunchKernelGGL(jac_block_kernel<16>, dim3(p.nbc / 2), dim3(1024), p.lds, st, w.JB, w.JV, b, b, p.nbc, round,
+                           tol, w.flags, tuning("jacobi_local_sweeps", 1));
+      else
+        hipLaunchKernelGGL(jac_round_kernel, dim3(p.nbc / 2), dim3(p.nt), p.lds, st, w.JB, w.JV, b, b, p.w, p.nbc,
+                           round, tol, w.flags, 1);
     }
     hipLaunchKernelGGL(jac_sweep_end_kernel, dim3(1), dim3(64), 0, st, w.flags);
     FLGP_TRY(check_launch("jac_round_kernel"));
