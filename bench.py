@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=20000, help="rows of the bounded CPU-baseline sample")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--tune", action="append", default=[], help="key=value tuning knobs (experiments)")
     return ap.parse_args()
 
 
@@ -116,6 +117,9 @@ def main():
     stages = HipStages(device)
     path = HeatKernelPath(stages)
     L = _lib.lib()
+    for kv in args.tune:
+        k, v = kv.split("=")
+        L.flgp_set_tuning(k.encode(), int(v))
 
     n, d, s = args.n, args.d, args.s
     lo, hi = shard_bounds(n, world, rank)
@@ -167,7 +171,7 @@ def main():
 
     # ---- per-kernel numbers from the timed region (HIP events on the launch stream)
     kernels = {}
-    for name in ["gemm_f64_kernel", "knn_kernel", "lae_kernel", "gram_kernel", "u_recover_kernel", "csc_build", "colsum_kernel", "jacobi_eig", "jacobi_refine"]:
+    for name in ["gemm_f64_kernel", "knn_kernel", "lae_kernel", "gram_kernel", "u_recover_kernel", "csc_build", "colsum_kernel", "jacobi_eig", "jacobi_refine", "gemm_large", "gemm_medium", "gemm_small"]:
         c, ms, w = prof_query(L, name)
         if c:
             kernels[name] = {"launches_per_step": c / args.steps, "ms_per_step": ms / args.steps,

@@ -542,7 +542,7 @@ struct EigWork {
 static size_t align_up(size_t x) { return (x + 255) / 256 * 256; }
 
 static int eig_block_size(int s, int K) {
-  int guard = K / 4;
+  int guard = K * tuning("eig_guard_pct", 25) / 100;
   if (guard < 24) guard = 24;
   int b = K + guard;
   b = (b + 15) / 16 * 16;
@@ -896,7 +896,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     const double g1 = (top - c) / e;            // >= 1
     // degree: amplification T_m(g1) of the top direction capped per outer iteration
     // (gentler while the block is still far from the invariant subspace)
-    const double amp = (it < 2) ? 1e3 : 1e7;
+    const double amp = (it < 2) ? 1e3 : std::pow(10.0, (double)tuning("eig_amp_exp", 7));
     int m = (int)std::floor(std::acosh(amp) / std::acosh(std::max(g1, 1.0 + 1e-12)));
     m = std::max(2, std::min(m, 40));
     const double sigma1 = e / (top - c);

@@ -214,6 +214,9 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
   g.part = work;
   {
     ProfScope ps("gemm_f64_kernel", st, 2.0 * (double)M * (double)N * (double)Kd);
+    // second record per shape class (large / medium / small) for the bench breakdown
+    const double fl = 2.0 * (double)M * (double)N * (double)Kd;
+    ProfScope ps2(fl > 5e9 ? "gemm_large" : (fl > 2e8 ? "gemm_medium" : "gemm_small"), st, fl);
     hipLaunchKernelGGL(gemm_f64_kernel, dim3(ntiles, 1, nsplit), dim3(256), 0, st, g);
   }
   FLGP_TRY(check_launch("gemm_f64_kernel"));
