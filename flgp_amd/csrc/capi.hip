@@ -126,7 +126,7 @@ int csr_out(Sim &S, hipStream_t st, int *csr_p, int *csr_j, double *csr_x) {
 // spectrum_from_Z_cpp on the device ELL (reference src/Spectrum.cpp:146-161): leaves values (K)
 // and vectors (n x K) on the device
 struct Spectrum {
-  DevBuf G, eig, V, values, vectors, work;
+  DevBuf G, eig, V, values, vectors, work, uwork;
   int K = 0;
 };
 
@@ -151,9 +151,10 @@ int spectrum(Sim &S, hipStream_t st, int K, int root, Spectrum &P, int *info) {
   // u = A v / sigma, vectors = u sqrt(n), values = sigma^2 (or sigma if root)  (:153-158)
   FLGP_TRY(P.values.alloc(sizeof(double) * (size_t)K));
   FLGP_TRY(P.vectors.alloc(sizeof(double) * (size_t)S.n * K));
+  FLGP_TRY(P.uwork.alloc(flgp_dev_u_recover_workspace(S.s, K)));
   return flgp_dev_u_recover(st, S.ell_idx.as<int>(), S.ell_val.as<double>(), S.n, S.r, P.V.as<double>(), S.s, S.s,
                             P.eig.as<double>(), K, std::sqrt((double)S.n), root, P.vectors.as<double>(), S.n,
-                            P.values.as<double>());
+                            P.values.as<double>(), P.uwork.as<double>());
 }
 
 int parse_kernel(const char *kernel, int *se) {

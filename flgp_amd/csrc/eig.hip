@@ -373,6 +373,72 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
   store_panel(V);
 }
 
+// Symmetric eigendecomposition of a small matrix (g <= N) by one workgroup: classical two-sided
+// cyclic Jacobi, the whole matrix and the rotation product in LDS, every round = NP leader lanes
+// computing rotations + every thread rebuilding its elements of J^T A J and W J into the other
+// buffers (two barriers per round).  Used for the dense guard block of the Rayleigh-Ritz matrix.
+template <int N>
+__global__ __launch_bounds__(1024) void small_sym_eig_kernel(const double *__restrict__ T, int ldt, int g,
+                                                             double *__restrict__ Vout, double tol, int max_sweeps) {
+  constexpr int NP = N / 2;
+  extern __shared__ double sm[];
+  __shared__ int any_rot;
+  double *Gc = sm, *Gn = sm + N * N, *Wc = sm + 2 * N * N, *Wn = sm + 3 * N * N;
+  double *cc = sm + 4 * N * N, *dd = cc + N;
+  int *pr = (int *)(dd + N);
+  const int tid = threadIdx.x;
+  for (int e = tid; e < N * N; e += 1024) {
+    const int i = e / N, j = e % N;
+    Gc[e] = (i < g && j < g) ? 0.5 * (T[(size_t)j * ldt + i] + T[(size_t)i * ldt + j]) : 0.0;
+    Wc[e] = (i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  const double tol2 = tol * tol;
+  for (int sw = 0; sw < max_sweeps; ++sw) {
+    if (tid == 0) any_rot = 0;
+    __syncthreads();
+    int rot_here = 0;
+    for (int rr = 0; rr < N - 1; ++rr) {
+      if (tid < NP) {
+        int p, q;
+        rr_pair(N, rr, tid, p, q);
+        const double al = Gc[p * N + p], be = Gc[q * N + q], ga = Gc[p * N + q];
+        double cs = 1.0, sn = 0.0;
+        if (ga * ga > tol2 * __builtin_fabs(al * be) && ga != 0.0) {
+          const double dl = be - al;
+          const double r1 = rsqrt_nr(dl * dl + 4.0 * (ga * ga));
+          const double x2 = 0.5 + 0.5 * (__builtin_fabs(dl) * r1);
+          const double r2 = rsqrt_nr(x2);
+          cs = x2 * r2;
+          sn = (dl >= 0.0 ? ga : -ga) * (r1 * r2);
+          ++rot_here;
+        }
+        cc[p] = cs; dd[p] = -sn; pr[p] = q;
+        cc[q] = cs; dd[q] = sn;  pr[q] = p;
+      }
+      __syncthreads();
+      for (int e = tid; e < N * N; e += 1024) {
+        const int i = e / N, j = e % N;
+        const int pi = pr[i], pj = pr[j];
+        const double ci = cc[i], di = dd[i], cj = cc[j], dj = dd[j];
+        Gn[e] = ci * (cj * Gc[i * N + j] + dj * Gc[i * N + pj]) + di * (cj * Gc[pi * N + j] + dj * Gc[pi * N + pj]);
+        Wn[e] = cj * Wc[i * N + j] + dj * Wc[i * N + pj];
+      }
+      __syncthreads();
+      double *t1 = Gc; Gc = Gn; Gn = t1;
+      double *t2 = Wc; Wc = Wn; Wn = t2;
+    }
+    if (rot_here) any_rot = 1;
+    __syncthreads();
+    if (!any_rot) break;
+    __syncthreads();
+  }
+  for (int e = tid; e < g * g; e += 1024) {
+    const int i = e % g, j = e / g;
+    Vout[e] = Wc[i * N + j];   // column-major g x g: column j = eigenvector j
+  }
+}
+
 // keep the strictly upper triangle (i < j) of the b x b matrix C, zero the rest
 __global__ void mask_strict_upper_kernel(double *__restrict__ C, int b) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -647,23 +713,22 @@ static int jacobi_eig(hipStream_t st, const double *T, int ldt, int b, EigWork &
 static int jacobi_refine(hipStream_t st, const double *T, int b, int K, EigWork &w, std::vector<double> &h_lam,
                          int *sweeps_out, int sweeps) {
   const int g = b - K;
-  const size_t lds_small = sizeof(double) * 4 * (size_t)((g + 1) / 2) * (g + 16);
-  if (g < 2 || lds_small > 150 * 1024 || 2 * (size_t)g * g > (size_t)b * b)
+  if (g < 2 || g > 64 || 2 * (size_t)g * g > (size_t)b * b)
     return jacobi_eig(st, T, b, b, w, h_lam, sweeps_out, -1, 1.0);
   ProfScope ps("jacobi_refine", st, 8.0 * (double)b * b);
-  double *Bg = w.X2, *Vg = w.X2 + (size_t)g * g;
-  const int wg = (g + 1) / 2;
-  hipLaunchKernelGGL(jac_init_kernel, dim3(ceil_div((long)g * g, 256)), dim3(256), 0, st, T + (size_t)K * b + K, b,
-                     g, Bg, Vg, g, w.flags);
-  FLGP_HIP(hipFuncSetAttribute((const void *)jac_round_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               150 * 1024));
+  double *Vg = w.X2;
+  const size_t lds_small = sizeof(double) * (4 * 64 * 64 + 2 * 64) + sizeof(int) * 64;
+  FLGP_HIP(hipFuncSetAttribute((const void *)small_sym_eig_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                               (int)lds_small));
   const double tol_g = 4.0 * std::sqrt((double)g) * 1.1102230246251565e-16;
-  hipLaunchKernelGGL(jac_round_kernel, dim3(1), dim3(1024), lds_small, st, Bg, Vg, g, g, wg, 2, 0, tol_g, w.flags, 40);
-  FLGP_TRY(check_launch("jac_round_kernel(guard block)"));
+  hipLaunchKernelGGL(small_sym_eig_kernel<64>, dim3(1), dim3(1024), lds_small, st, T + (size_t)K * b + K, b, g, Vg,
+                     tol_g, 30);
+  FLGP_TRY(check_launch("small_sym_eig_kernel"));
   hipLaunchKernelGGL(embed_block_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, Vg, g, K, b, w.JV);
   FLGP_TRY(check_launch("embed_block_kernel"));
   // JB = T JV
-  FLGP_TRY(gemm_launch(st, b, b, b, 1.0, T, 1, b, w.JV, 1, b, 0.0, nullptr, 0, 0, w.JB, 1, b, nullptr, 0, 0.0, nullptr));
+  FLGP_TRY(gemm_launch(st, b, b, b, 1.0, T, 1, b, w.JV, 1, b, 0.0, nullptr, 0, 0, w.JB, 1, b, w.gemm_ws, w.gemm_ws_elems,
+                       0.0, nullptr));
   return jacobi_run(st, b, w, h_lam, sweeps_out, sweeps, 1.0, false);
 }
 

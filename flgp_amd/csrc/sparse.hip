@@ -219,6 +219,57 @@ __global__ __launch_bounds__(256) void u_recover_kernel(const int *__restrict__ 
   }
 }
 
+// Vt(j, k) = V(j, k) stored k-contiguous: Vt[j*K + k]  (V: s x K column-major, ld = ldv)
+__global__ void transpose_v_kernel(const double *__restrict__ V, int ldv, int s, int K, double *__restrict__ Vt) {
+  __shared__ double t[32][33];
+  const int j0 = blockIdx.x * 32, k0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
+  for (int kk = ty; kk < 32; kk += 8) {
+    const int j = j0 + tx, k = k0 + kk;
+    t[kk][tx] = (j < s && k < K) ? V[(size_t)k * ldv + j] : 0.0;
+  }
+  __syncthreads();
+  for (int jj = ty; jj < 32; jj += 8) {
+    const int j = j0 + jj, k = k0 + tx;
+    if (j < s && k < K) Vt[(size_t)j * K + k] = t[tx][jj];
+  }
+}
+
+// U-recovery, gather form: a workgroup owns 64 rows x 64 eigen-columns.  Lanes run along k, so the
+// r rows of Vt a point needs are read as contiguous 512-byte pieces (they come from L2: Vt is
+// s*K*8 bytes); the 64 x 64 tile is turned through LDS so that the column-major output is written
+// in 512-byte pieces as well.  Arithmetic as u_recover_kernel: acc = 0; acc += A(i,a) V(idx,k)
+// (a ascending, mul then add); (acc / sigma_k) * scale.
+__global__ __launch_bounds__(256) void u_recover_tiled_kernel(const int *__restrict__ ell_idx,
+                                                              const double *__restrict__ val, int n, int r,
+                                                              const double *__restrict__ Vt,
+                                                              const double *__restrict__ eig, int K, double scale,
+                                                              double *__restrict__ out, int ldo) {
+  __shared__ double tile[64][65];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long i0 = (long)blockIdx.x * 64;
+  const int k0 = blockIdx.y * 64;
+  const int k = k0 + lane;
+  const bool kok = k < K;
+  double sigma = 1.0;
+  if (kok) { const double ev = eig[k]; sigma = __builtin_sqrt(ev > 0.0 ? ev : 0.0); }
+  for (int il = wave * 16; il < wave * 16 + 16; ++il) {
+    const long i = i0 + il;
+    double acc = 0.0;
+    if (i < n && kok) {
+      const int *id = ell_idx + (size_t)i * r;      // wave-uniform addresses: scalar loads
+      const double *va = val + (size_t)i * r;
+      for (int a = 0; a < r; ++a) acc += va[a] * Vt[(size_t)id[a] * K + k];
+    }
+    tile[lane][il] = (acc / sigma) * scale;
+  }
+  __syncthreads();
+  const int i = tid & 63;
+  if (i0 + i < n)
+    for (int kq = tid >> 6; kq < 64; kq += 4)
+      if (k0 + kq < K) out[(size_t)(k0 + kq) * ldo + i0 + i] = tile[kq][i];
+}
+
 __global__ void values_out_kernel(const double *__restrict__ eig, int K, int root, double *__restrict__ values) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= K) return;
@@ -324,16 +375,24 @@ extern "C" int flgp_dev_gram(void *stream, const int *d_ell_idx, const double *d
   return check_launch("gram_kernel");
 }
 
+extern "C" size_t flgp_dev_u_recover_workspace(int s, int K) { return sizeof(double) * (size_t)s * K + 256; }
+
 extern "C" int flgp_dev_u_recover(void *stream, const int *d_ell_idx, const double *d_ell_val, int n, int r,
                                   const double *dV, int ldv, int s, const double *d_eig, int K, double scale,
-                                  int root, double *d_vectors, int ldo, double *d_values_out) {
-  (void)s;
+                                  int root, double *d_vectors, int ldo, double *d_values_out, double *d_work) {
   hipStream_t st = (hipStream_t)stream;
   FLGP_REQUIRE(r >= 1 && r <= FLGP_RMAX && K >= 1 && ldo >= n, "u_recover: bad shape");
   if (n > 0) {
     ProfScope ps("u_recover_kernel", st, 12.0 * (double)n * r + 8.0 * (double)s * K + 8.0 * (double)n * K);
-    hipLaunchKernelGGL(u_recover_kernel, dim3(ceil_div(n, 256), ceil_div(K, 8)), dim3(256), 0, st, d_ell_idx,
-                       d_ell_val, n, r, dV, ldv, d_eig, K, scale, d_vectors, ldo);
+    if (d_work) {
+      hipLaunchKernelGGL(transpose_v_kernel, dim3(ceil_div(s, 32), ceil_div(K, 32)), dim3(256), 0, st, dV, ldv, s, K,
+                         d_work);
+      hipLaunchKernelGGL(u_recover_tiled_kernel, dim3(ceil_div(n, 64), ceil_div(K, 64)), dim3(256), 0, st, d_ell_idx,
+                         d_ell_val, n, r, d_work, d_eig, K, scale, d_vectors, ldo);
+    } else {
+      hipLaunchKernelGGL(u_recover_kernel, dim3(ceil_div(n, 256), ceil_div(K, 8)), dim3(256), 0, st, d_ell_idx,
+                         d_ell_val, n, r, dV, ldv, d_eig, K, scale, d_vectors, ldo);
+    }
     FLGP_TRY(check_launch("u_recover_kernel"));
   }
   if (d_values_out) {
