@@ -185,6 +185,13 @@ def main():
                 "launches_per_step": c / args.steps, "avg_launch_ms": ms / c,
                 "algorithmic_flops_per_launch": w / c}
 
+    if roof:
+        try:   # HBM bytes per launch of that kernel, from the committed rocprofv3 PMC passes (profiles/)
+            pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["gemm_f64_kernel"]
+            roof["traffic"] = pm["hbm_bytes_per_launch"]
+            roof["traffic_source"] = pm["source"]
+        except Exception:
+            roof["traffic"] = None
     out = {
         "metric": "points/sec through k-NN->Laplacian->trunc-SVD->heat-cov, n=1e6 d=16 K=200",
         "value": n / (ms_per_step * 1e-3), "unit": "points/s", "n_gpus": world, "steps": args.steps,
