@@ -142,6 +142,11 @@ __global__ __launch_bounds__(256) void knn_kernel(const double *__restrict__ X, 
     for (int jj = 0; jj < TA; jj += A) {
       const double *__restrict__ ug = Ut + (size_t)(j0 + jj) * DP;  // wave-uniform -> s_load
       const double *ul = tile + jj * DP;                              // wave-uniform -> broadcast ds_read
+      // the A squared norms in one scalar load at the top of the step: fetched one by one between
+      // the compare/branch blocks they each cost an exposed scalar-cache round trip
+      double uug[A];
+#pragma unroll
+      for (int a = 0; a < A; ++a) uug[a] = uu[j0 + jj + a];
       double acc[P][A];
 #pragma unroll
       for (int a = 0; a < A; ++a) {
@@ -161,7 +166,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const double *__restrict__ X, 
       bool full = false;
 #pragma unroll
       for (int a = 0; a < A; ++a) {
-        const double uuj = uu[j0 + jj + a];
+        const double uuj = uug[a];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           const double D = __builtin_fma(-2.0, acc[p][a], xx[p]) + uuj;
@@ -235,10 +240,12 @@ extern "C" int flgp_dev_anchor_prep(void *stream, const double *dU, int s, int l
 #define KNN_ARGS st, dX, n, ldx, d, dUt, duu, s, r, d_idx, d_dist, ldo
 // default shape per padded dimension: one point per lane, A anchors per step, the first KS
 // coordinates as SGPR operands (measured on MI355X at n=1e6, d=16, s=5000, r=10:
-// P1/A4/KS8 6.9 ms, P1/A4/KS0 7.7 ms, P2/A2/KS16 9.0 ms, P2/A4/KS0 12.6 ms -- gpurun_out/exp_knn2.log)
+// P1/A2/KS8 5.8 ms, P1/A4/KS8 6.7 ms, P1/A4/KS0 7.4 ms, P1/A2/KS16 10.7 ms, P2/A4/KS8 10.6 ms: fewer
+// VGPRs (3 waves/SIMD) beat more chains per wave; an all-scalar operand stream starves on the scalar cache)
 #define KNN_CASE(DPv, RCv)                                                                   \
   if (dpad == DPv && rcap == RCv) {                                                          \
-    if constexpr (DPv <= 16) return launch_knn<DPv, RCv, 1, 4, DPv / 2, 12>(KNN_ARGS);       \
+    if constexpr (DPv == 16) return launch_knn<DPv, RCv, 1, 2, 8, 8>(KNN_ARGS);              \
+    else if constexpr (DPv < 16) return launch_knn<DPv, RCv, 1, 4, DPv / 2, 12>(KNN_ARGS);   \
     else return launch_knn<DPv, RCv, 1, 2, 16, 8>(KNN_ARGS);                                 \
   }
 
@@ -258,6 +265,12 @@ extern "C" int flgp_dev_knn(void *stream, const double *dX, int n, int ldx, int 
     if (variant == 1) return launch_knn<16, 16, 2, 4, 8, 12>(KNN_ARGS);
     if (variant == 2) return launch_knn<16, 16, 2, 2, 16, 8>(KNN_ARGS);
     if (variant == 4) return launch_knn<16, 16, 1, 4, 0, 12>(KNN_ARGS);
+    if (variant == 5) return launch_knn<16, 16, 1, 2, 16, 8>(KNN_ARGS);
+    if (variant == 6) return launch_knn<16, 16, 1, 2, 8, 8>(KNN_ARGS);
+    if (variant == 7) return launch_knn<16, 16, 1, 2, 4, 8>(KNN_ARGS);
+    if (variant == 8) return launch_knn<16, 16, 1, 2, 12, 8>(KNN_ARGS);
+    if (variant == 9) return launch_knn<16, 16, 1, 1, 8, 8>(KNN_ARGS);
+    if (variant == 10) return launch_knn<16, 16, 1, 2, 0, 8>(KNN_ARGS);
   }
   KNN_CASE(4, 4) KNN_CASE(4, 8) KNN_CASE(4, 16) KNN_CASE(4, 32)
   KNN_CASE(8, 4) KNN_CASE(8, 8) KNN_CASE(8, 16) KNN_CASE(8, 32)

@@ -41,7 +41,7 @@ def main():
     t0 = time.time()
     oidx, odist = O.knn(X[:ncheck], U, r, output=True)
     print(f"oracle knn on {ncheck} rows: {time.time()-t0:.2f}s ({O.threads()} threads)", flush=True)
-    for variant, name in [(0, "P2 A4 KS0"), (1, "P2 A4 KS8"), (2, "P2 A2 KS16"), (3, "P2 A2 KS0"), (4, "P1 A4 KS0"), (5, "P2 A4 KS4"), (6, "P1 A8 KS0"), (7, "P1 A4 KS8")]:
+    for variant, name in [(6, "P1 A2 KS8"), (7, "P1 A2 KS4"), (8, "P1 A2 KS12"), (9, "P1 A1 KS8"), (10, "P1 A2 KS0")]:
         L.flgp_set_tuning(b"knn_variant", variant)
         didx.zero_(); ddist.zero_()
         rc = L.flgp_dev_knn(st, dX.data_ptr(), n, n, d, dUt.data_ptr(), duu.data_ptr(), s, r, didx.data_ptr(), ddist.data_ptr(), n)
