@@ -43,6 +43,7 @@ _SIGNATURES = {
                                           c_int, c_double, P, P]),
     "flgp_heat_kernel_covariance": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, c_double, c_int,
                                             c_char_p, c_char_p, c_int, c_double, P]),
+    "flgp_se_spectrum_grid": (c_int, [P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, c_char_p, c_int, P, P, P, c_int]),
     "flgp_lae_eigenmap": (c_int, [P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_char_p, P, P]),
     # device-pointer stage entry points
     "flgp_dev_anchor_dpad": (c_int, [c_int]),
@@ -51,6 +52,8 @@ _SIGNATURES = {
     "flgp_dev_knn": (c_int, [P, P, c_int, c_int, c_int, P, P, c_int, c_int, P, P, c_int]),
     "flgp_dev_lae": (c_int, [P, P, c_int, c_int, c_int, P, c_int, c_int, P, c_int, P, P]),
     "flgp_dev_v_to_z": (c_int, [P, P, c_int, P]),
+    "flgp_dev_se_weights_den": (c_int, [P, P, P, c_int, c_int, c_int, c_double, P, P]),
+    "flgp_dev_mean": (c_int, [P, P, c_long, P, P]),
     "flgp_dev_se_weights": (c_int, [P, P, P, c_int, c_int, c_int, c_double, P, P]),
     "flgp_dev_csc_workspace": (c_size_t, [c_int, c_int, c_int]),
     "flgp_dev_csc_build": (c_int, [P, P, c_int, c_int, c_int, P, P, P, c_size_t]),

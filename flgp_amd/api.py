@@ -110,15 +110,6 @@ def local_anchor_embedding_cpp(x, U):
     return z.reshape(1, -1)
 
 
-def _similarity_call(fn, X, U, r, *extra):
-    X = _f64(X, "X"); U = _f64(U, "U")
-    n, d = X.shape; s = U.shape[0]
-    p = np.zeros(n + 1, dtype=np.int32)
-    j = np.zeros(n * r, dtype=np.int32)
-    x = np.zeros(n * r, dtype=np.float64)
-    return X, U, n, d, s, p, j, x
-
-
 def LAE_cpp(X, U, r=3):
     """LAE_cpp (src/lae.cpp:48-70) -> CSR n x s with exactly r stored entries per row."""
     X = _f64(X, "X"); U = _f64(U, "U")
@@ -166,14 +157,6 @@ def spectrum_from_Z_cpp(Z, K, root=False):
     values = np.zeros(Kk); vectors = np.zeros((n, Kk), order="F")
     check(_lib.lib().flgp_spectrum_from_Z(_ptr(j), _ptr(x), n, s, r, int(K), int(bool(root)), _ptr(values), _ptr(vectors)))
     return EigenPair(values, vectors)
-
-
-def truncated_SVD_cpp(Z, K=-1):
-    """truncated_SVD_cpp (src/TruncatedSVD.cpp:9-34) on a matrix that is already scaled:
-    values = sigma^2, vectors = left singular vectors.  Provided through spectrum_from_Z_cpp's
-    device path by undoing its two scalings is not possible, so this mirrors the reference only
-    for matrices whose columns are already unit-scaled; use spectrum_from_Z_cpp."""
-    raise NotImplementedError("use spectrum_from_Z_cpp: the column scaling is fused into the device path")
 
 
 def HK_from_spectrum_cpp(eigenpair, K, t, idx0, idx1):
@@ -251,6 +234,28 @@ def heat_kernel_covariance_rcpp(X, X_new, s, r, t, K=-1, models=None, epsilon=0.
     (gl="cluster-normalized", root=TRUE, K=-1)."""
     models = dict(_DEFAULT_MODELS_R, **(models or {}))
     return heat_kernel_covariance_cpp(X, X_new, s, r, t, K, models, nstart, epsilon, U=U)
+
+
+def se_spectrum_grid(X, X_new, s, r, K=-1, a2s=None, models=None, nstart=1, U=None, max_parallel=10):
+    """The spectrum part of fit_se_{regression,logit,logit_mult}_gp_cpp (src/Fit.cpp:127-178): one k-NN with
+    distances, then one EigenPair per bandwidth a2 (Z = exp(-dist/(a2 mean(dist))), Laplacian, truncated SVD).
+    Defaults: a2s = exp(seq(log(0.1), log(10), length.out = 10)) (R/Fit.R:128-130), models as R/Fit.R:121-124.
+    Returns (list of EigenPair, distances_mean)."""
+    models = dict(_DEFAULT_MODELS_R, **(models or {}))
+    if a2s is None:
+        a2s = np.exp(np.linspace(np.log(0.1), np.log(10.0), 10))
+    a2s = np.ascontiguousarray(a2s, dtype=np.float64)
+    X = _f64(X, "X"); X_new = _f64(X_new, "X_new")
+    X_all = np.asfortranarray(np.vstack([X, X_new]))
+    n, d = X_all.shape
+    U = _anchors(X_all, s, models, U, nstart)
+    Kk = s if K < 0 else int(K)
+    values = np.zeros((a2s.size, Kk)); vectors = np.zeros((a2s.size, Kk, n))   # block i: n x K column-major
+    mean = np.zeros(1)
+    check(_lib.lib().flgp_se_spectrum_grid(_ptr(X_all), n, d, _ptr(U), s, U.shape[1], int(r), int(K), _ptr(a2s), a2s.size,
+                                           _b(models["gl"]), int(bool(models["root"])), _ptr(values), _ptr(vectors),
+                                           _ptr(mean), int(max_parallel)))
+    return [EigenPair(values[i].copy(), np.asfortranarray(vectors[i].T)) for i in range(a2s.size)], float(mean[0])
 
 
 def lae_eigenmap(X, s, r=3, ndim=2, subsample="kmeans", norm="cluster-normalized", nstart=1, U=None):

@@ -3,6 +3,8 @@
 // copies the result back; no state survives the call (as the reference: no handles/caches).
 #include "common.h"
 #include <cmath>
+#include <string>
+#include <thread>
 #include <vector>
 
 using namespace flgp;
@@ -10,6 +12,9 @@ using namespace flgp;
 extern "C" int flgp_dev_anchor_rows(int s);
 extern "C" int flgp_dev_v_to_z(void *stream, const double *d_v, int r, double *d_z);
 extern "C" size_t flgp_dev_hk_workspace(int n0, int n1, int K, int gather0);
+extern "C" int flgp_dev_mean(void *stream, const double *d_x, long count, double *d_out, double *d_work);
+extern "C" int flgp_dev_se_weights_den(void *stream, const int *d_knn_idx, const double *d_knn_dist, int n, int ldk,
+                                       int r, double den, int *d_ell_idx, double *d_ell_val);
 
 namespace {
 
@@ -383,5 +388,99 @@ extern "C" int flgp_lae_eigenmap(const double *X, int n, int d, const double *U,
   FLGP_REQUIRE(eigenvalues && eigenvectors && ndim >= 1, "lae_eigenmap: bad arguments");
   FLGP_TRY(flgp_heat_kernel_spectrum(X, n, d, U, s, ucols, r, ndim, "lae", norm, 1, 0.0, eigenvalues, eigenvectors));
   for (int k = 0; k < ndim; ++k) eigenvalues[k] = 1.0 - eigenvalues[k];
+  return FLGP_OK;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// SE-kernel bandwidth grid: the spectrum part of fit_se_*_gp_cpp
+// (reference src/Fit.cpp:127-178, :694-743, :820-867): ONE k-NN with distances, then for every
+// bandwidth a2:  Z = exp(-dist / (a2 * mean(dist)))  ->  graphLaplacian_cpp  ->  spectrum_from_Z_cpp.
+// The reference runs the l (default 10) truncated SVDs one after the other through R; here the k-NN,
+// the ELL/CSC pattern and the cluster sizes are shared and the l spectra run concurrently, one host
+// thread + one HIP stream each (the small dense eigen-kernels of one solve occupy a few CUs only).
+// values: l x K (row i = bandwidth i), vectors: l blocks of n x K column-major.
+// ---------------------------------------------------------------------------------------------
+extern "C" int flgp_se_spectrum_grid(const double *X_all, int n, int d, const double *U, int s, int ucols, int r,
+                                     int K, const double *a2s, int l, const char *gl, int root, double *values,
+                                     double *vectors, double *distances_mean_out, int max_parallel) {
+  const int glc = flgp_parse_gl(gl);
+  if (glc < 0) return glc;
+  FLGP_REQUIRE(a2s && l >= 1 && values && vectors, "se_spectrum_grid: bad arguments");
+  if (K < 0) K = s;
+  FLGP_REQUIRE(K >= 1 && K <= s, "need 1 <= K <= s (K=%d, s=%d)", K, s);
+  Stream st;
+  FLGP_TRY(st.create());
+  Sim S;
+  FLGP_TRY(upload_points(S, st.s, X_all, n, d, U, s, ucols, glc == FLGP_GL_CLUSTER_NORMALIZED));
+  FLGP_TRY(run_knn(S, st.s, r, true));
+  FLGP_TRY(alloc_ell(S));
+  // pattern (sorted by column) and the mean distance; the weights of this first call are discarded
+  FLGP_TRY(flgp_dev_se_weights_den(st.s, S.knn_idx.as<int>(), S.knn_dist.as<double>(), n, n, r, 1.0, S.ell_idx.as<int>(),
+                                   S.ell_val.as<double>()));
+  FLGP_TRY(build_csc(S, st.s));
+  DevBuf dmean, mwork;
+  FLGP_TRY(dmean.alloc(sizeof(double)));
+  FLGP_TRY(mwork.alloc(sizeof(double) * (size_t)(((long)n * r + 4095) / 4096 + 1)));
+  FLGP_TRY(flgp_dev_mean(st.s, S.knn_dist.as<double>(), (long)n * r, dmean.as<double>(), mwork.as<double>()));
+  double mean = 0.0;
+  FLGP_TRY(d2h(&mean, dmean.p, sizeof(double), st.s));
+  FLGP_HIP(hipStreamSynchronize(st.s));
+  if (distances_mean_out) *distances_mean_out = mean;
+  const double *sizes = (ucols == d + 1) ? S.U.as<double>() + (size_t)d * s : nullptr;
+  int dev = 0;
+  FLGP_HIP(hipGetDevice(&dev));
+
+  std::vector<int> rcs(l, FLGP_OK);
+  std::vector<std::string> msgs(l);
+  auto work = [&](int i) -> int {
+    FLGP_HIP(hipSetDevice(dev));
+    Stream ws;
+    FLGP_TRY(ws.create());
+    Sim W;   // shares pattern / CSC with S, owns its values
+    W.n = n; W.d = d; W.s = s; W.r = r;
+    FLGP_TRY(W.ell_val.alloc(sizeof(double) * (size_t)n * r));
+    FLGP_TRY(W.colsum.alloc(sizeof(double) * (size_t)s));
+    DevBuf scratch_idx;
+    FLGP_TRY(scratch_idx.alloc(sizeof(int) * (size_t)n * r));
+    FLGP_TRY(flgp_dev_se_weights_den(ws.s, S.knn_idx.as<int>(), S.knn_dist.as<double>(), n, n, r, a2s[i] * mean,
+                                     scratch_idx.as<int>(), W.ell_val.as<double>()));
+    const int *eidx = S.ell_idx.as<int>();
+    const int *colptr = S.colptr.as<int>(), *pos = S.pos.as<int>();
+    if (glc != FLGP_GL_RW) {
+      FLGP_TRY(flgp_dev_colsum(ws.s, W.ell_val.as<double>(), colptr, pos, s, W.colsum.as<double>()));
+      FLGP_TRY(flgp_dev_col_scale(ws.s, eidx, W.ell_val.as<double>(), n, r, W.colsum.as<double>(),
+                                  glc == FLGP_GL_CLUSTER_NORMALIZED ? sizes : nullptr, 0));
+    }
+    FLGP_TRY(flgp_dev_row_normalize(ws.s, W.ell_val.as<double>(), n, r));
+    FLGP_TRY(flgp_dev_colsum(ws.s, W.ell_val.as<double>(), colptr, pos, s, W.colsum.as<double>()));
+    FLGP_TRY(flgp_dev_col_scale(ws.s, eidx, W.ell_val.as<double>(), n, r, W.colsum.as<double>(), nullptr, 1));
+    DevBuf G, eig, V, vals, vecs, ework, uwork;
+    FLGP_TRY(G.alloc(sizeof(double) * (size_t)s * s));
+    FLGP_TRY(flgp_dev_gram(ws.s, eidx, W.ell_val.as<double>(), n, s, r, colptr, pos, G.as<double>(), s));
+    const size_t wb = flgp_dev_eig_workspace(s, K);
+    FLGP_TRY(ework.alloc(wb));
+    FLGP_TRY(eig.alloc(sizeof(double) * (size_t)K));
+    FLGP_TRY(V.alloc(sizeof(double) * (size_t)s * K));
+    FLGP_TRY(flgp_dev_eig_topk(ws.s, G.as<double>(), s, s, K, 0.0, eig.as<double>(), V.as<double>(), s, ework.p, wb, nullptr));
+    FLGP_TRY(vals.alloc(sizeof(double) * (size_t)K));
+    FLGP_TRY(vecs.alloc(sizeof(double) * (size_t)n * K));
+    FLGP_TRY(uwork.alloc(flgp_dev_u_recover_workspace(s, K)));
+    FLGP_TRY(flgp_dev_u_recover(ws.s, eidx, W.ell_val.as<double>(), n, r, V.as<double>(), s, s, eig.as<double>(), K,
+                                std::sqrt((double)n), root, vecs.as<double>(), n, vals.as<double>(), uwork.as<double>()));
+    FLGP_TRY(d2h(values + (size_t)i * K, vals.p, sizeof(double) * (size_t)K, ws.s));
+    FLGP_TRY(d2h(vectors + (size_t)i * n * K, vecs.p, sizeof(double) * (size_t)n * K, ws.s));
+    FLGP_HIP(hipStreamSynchronize(ws.s));
+    return FLGP_OK;
+  };
+  if (max_parallel < 1) max_parallel = 1;
+  for (int i0 = 0; i0 < l; i0 += max_parallel) {
+    std::vector<std::thread> th;
+    for (int i = i0; i < l && i < i0 + max_parallel; ++i)
+      th.emplace_back([&, i]() { rcs[i] = work(i); if (rcs[i] != FLGP_OK) msgs[i] = flgp_last_error(); });
+    for (auto &t : th) t.join();
+  }
+  for (int i = 0; i < l; ++i)
+    if (rcs[i] != FLGP_OK) { set_error("bandwidth %d (a2=%g): %s", i, a2s[i], msgs[i].c_str()); return rcs[i]; }
   return FLGP_OK;
 }

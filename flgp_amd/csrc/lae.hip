@@ -335,6 +335,52 @@ extern "C" int flgp_dev_v_to_z(void *stream, const double *d_v, int r, double *d
   return check_launch("v_to_z_kernel");
 }
 
+// fixed-shape two-level sum (deterministic): partial[b] = sum of a 4096-element slab in a fixed tree
+__global__ __launch_bounds__(256) void slab_sum_kernel(const double *__restrict__ x, long count, double *__restrict__ partial) {
+  __shared__ double red[256];
+  const long base = (long)blockIdx.x * 4096;
+  double acc = 0.0;
+  for (int k = 0; k < 16; ++k) {
+    const long e = base + k * 256 + threadIdx.x;
+    if (e < count) acc += x[e];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+__global__ void final_mean_kernel(const double *__restrict__ partial, int nparts, double denom, double *__restrict__ out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    double acc = 0.0;
+    for (int b = 0; b < nparts; ++b) acc += partial[b];
+    out[0] = acc / denom;
+  }
+}
+
+// mean of the n*r stored k-NN distances (distances_sp.coeffs().sum()/(n*r), reference src/Fit.cpp:131):
+// d_out[0]; d_work holds ceil(n*r/4096) doubles
+extern "C" int flgp_dev_mean(void *stream, const double *d_x, long count, double *d_out, double *d_work) {
+  FLGP_REQUIRE(count >= 1, "mean: empty input");
+  const int nparts = ceil_div(count, 4096);
+  hipLaunchKernelGGL(slab_sum_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, d_x, count, d_work);
+  hipLaunchKernelGGL(final_mean_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, d_work, nparts, (double)count, d_out);
+  return check_launch("mean kernels");
+}
+
+// Z = exp(-dist / den) on the stored entries, den given directly (den = a2 * mean(dist) in the fit_se_*
+// bandwidth grid, reference src/Fit.cpp:150)
+extern "C" int flgp_dev_se_weights_den(void *stream, const int *d_knn_idx, const double *d_knn_dist, int n, int ldk,
+                                       int r, double den, int *d_ell_idx, double *d_ell_val) {
+  FLGP_REQUIRE(r >= 1 && r <= FLGP_RMAX && ldk >= n, "SE weights: bad r / ldk");
+  if (n == 0) return FLGP_OK;
+  hipLaunchKernelGGL(se_weights_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, d_knn_idx,
+                     d_knn_dist, n, ldk, r, den, d_ell_idx, d_ell_val);
+  return check_launch("se_weights_kernel");
+}
+
 extern "C" int flgp_dev_se_weights(void *stream, const int *d_knn_idx, const double *d_knn_dist, int n, int ldk,
                                    int r, double epsilon, int *d_ell_idx, double *d_ell_val) {
   FLGP_REQUIRE(r >= 1 && r <= FLGP_RMAX && ldk >= n, "SE weights: bad r / ldk");

@@ -289,6 +289,27 @@ def cross_similarity(X, U, r, gl="rw", kernel="lae", epsilon=0.1):
     return eidx, graph_laplacian(eidx, zval, s, gl, num_class)
 
 
+def se_spectrum_grid(X_all, U, r, K, a2s, gl="cluster-normalized", root=True, method="auto"):
+    """Spectrum part of fit_se_*_gp_cpp (src/Fit.cpp:127-178): one k-NN with distances, then per
+    bandwidth a2: Z = exp(-dist/(a2*mean(dist))) (:150), graphLaplacian_cpp (:152-156),
+    spectrum_from_Z_cpp (:158).  Returns ([(values, vectors)], distances_mean)."""
+    X_all = _f64(X_all); U = _f64(U)
+    d = X_all.shape[1]; s = U.shape[0]
+    if K < 0:
+        K = s
+    kidx, kdist = knn(X_all, np.asfortranarray(U[:, :d]), r, output=True)
+    mean = float(kdist.sum() / kdist.size)                       # distances_sp.coeffs().sum()/(n*r) (:131)
+    num_class = np.ascontiguousarray(U[:, d]) if gl == "cluster-normalized" else None
+    out = []
+    for a2 in a2s:
+        order = np.argsort(kidx, axis=1, kind="stable")
+        eidx = np.ascontiguousarray(np.take_along_axis(kidx, order, axis=1), dtype=np.int32)
+        zval = np.ascontiguousarray(np.exp(-np.take_along_axis(kdist, order, axis=1) / (a2 * mean)))
+        zn = graph_laplacian(eidx, zval, s, gl, num_class)
+        out.append(spectrum_from_Z(eidx, zn, s, K, root=root, method=method))
+    return out, mean
+
+
 def heat_kernel_spectrum(X_all, U, r, K, kernel="lae", gl="rw", root=False, epsilon=0.1, method="auto"):
     """heat_kernel_spectrum_cpp (src/Spectrum.cpp:48-76) with the anchors U given
     (subsample_cpp, src/Utils.cpp:32-68, is outside the path: it calls R's kmeans)."""

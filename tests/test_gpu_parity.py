@@ -302,6 +302,32 @@ def test_end_to_end_c1_like(oracle):
     np.testing.assert_allclose(em["eigenvalues"], 1 - vals, rtol=0, atol=1e-10)
 
 
+def test_se_bandwidth_grid(oracle):
+    """the spectrum part of fit_se_*: one k-NN, ten bandwidths, spectra run concurrently."""
+    import time
+    n, d, s, r, K, m = 3000, 3, 300, 5, 30, 100
+    X, U0, U = make_case(n, d, s, r, seed=808)
+    a2s = np.exp(np.linspace(np.log(0.1), np.log(10.0), 10))        # R/Fit.R:128-130
+    t0 = time.perf_counter()
+    pairs, mean = api.se_spectrum_grid(X[:m], X[m:], s, r, K=K, a2s=a2s, U=U, max_parallel=10)
+    t_par = time.perf_counter() - t0
+    ref, omean = oracle.se_spectrum_grid(X, U, r, K, a2s)
+    assert abs(mean - omean) <= 1e-13 * omean
+    idx0 = np.arange(n, dtype=np.int32); idx1 = np.arange(m, dtype=np.int32)
+    for ep, (ov, ovec) in zip(pairs, ref):
+        np.testing.assert_allclose(ep.values, ov, rtol=EIG_RTOL, atol=1e-12)
+        H = oracle.hk_from_spectrum(ep.values, ep.vectors, K, 4.0, idx0, idx1)
+        Ho = oracle.hk_from_spectrum(ov, ovec, K, 4.0, idx0, idx1)
+        assert np.abs(H - Ho).max() <= H_RTOL * np.abs(Ho).max()
+    # same numbers one bandwidth at a time (the concurrency must not change results)
+    t0 = time.perf_counter()
+    seq, _ = api.se_spectrum_grid(X[:m], X[m:], s, r, K=K, a2s=a2s, U=U, max_parallel=1)
+    t_seq = time.perf_counter() - t0
+    for a, b in zip(pairs, seq):
+        np.testing.assert_array_equal(a.values, b.values)
+    print(f"SE grid: 10 spectra concurrent {t_par*1e3:.1f} ms, sequential {t_seq*1e3:.1f} ms")
+
+
 def test_pipeline_matches_host_entry_points(oracle, stages):
     n, d, s, r, K, m, t = 3000, 16, 300, 10, 40, 128, 6.0
     X, U0, U = make_case(n, d, s, r, seed=2024)
