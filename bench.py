@@ -108,12 +108,20 @@ def main():
                          f"python -m torch.distributed.run --nproc-per-node {args.gpus} bench.py --gpus {args.gpus} ...")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP library is the only implementation of this path")
+    # rehearsal knobs (one-GPU box): FLGP_FORCE_DEVICE pins every rank to one card and
+    # FLGP_DIST_BACKEND=gloo replaces RCCL, which refuses two ranks on the same device
+    if "FLGP_FORCE_DEVICE" in os.environ:
+        local_rank = int(os.environ["FLGP_FORCE_DEVICE"])
+    backend = os.environ.get("FLGP_DIST_BACKEND", "nccl")
     device = torch.device("cuda", local_rank)
     torch.cuda.set_device(device)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
     stages = HipStages(device)
     path = HeatKernelPath(stages)
     L = _lib.lib()

@@ -372,3 +372,47 @@ def test_full_size_properties(oracle, stages):
     ref = (res.vectors[:, :m].T * w) @ res.vectors[:, sl]                      # (m, 4096)
     got = res.H[:, sl]
     assert float((got - ref).abs().max()) <= 1e-10 * float(ref.abs().max())
+
+
+# ------------------------------------------------------------------------------ row sharding on the real stages
+def _shard_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)   # RCCL refuses two ranks on one card
+    try:
+        from flgp_amd.pipeline import shard_bounds
+        n, d, s, r, K, m, t = 6000, 16, 400, 10, 40, 300, 5.0
+        st = HipStages("cuda:0")
+        path = HeatKernelPath(st)
+        lo, hi = shard_bounds(n, world, rank)
+        X = synth.gaussian_mixture(hi - lo, d, components=5, seed=314, row_offset=lo)
+        sel = np.sort(synth.random_anchor_rows(n, s, seed=314))
+        mine = sel[(sel >= lo) & (sel < hi)] - lo
+        U = path.gather_anchors(torch.from_numpy(np.ascontiguousarray(X[mine].T)).cuda())
+        dX = cm(X)
+        sizes = path.cluster_sizes(dX, st.anchor_prep(U))
+        res = path.run(dX, U, PathConfig(s=s, r=r, K=K, t=t, m=m), n, lo, num_class=sizes)
+        np.save(os.path.join(out, f"H_{world}_{rank}.npy"), to_np_cm(res.H))
+        np.save(os.path.join(out, f"v_{world}_{rank}.npy"), res.values.cpu().numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_row_sharding_two_ranks_on_one_gpu(tmp_path):
+    """The multi-GPU driver (flgp_amd/pipeline.py) with the real HIP stages: two ranks share the one
+    card of this box over gloo and must reproduce the single-rank covariance (column sums and the
+    Gram matrix are reduced in a different association: rounding-level differences only)."""
+    import socket
+    import torch.multiprocessing as mp
+    out = str(tmp_path)
+    for world in (1, 2):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        mp.spawn(_shard_worker, args=(world, port, out), nprocs=world, join=True)
+    H1 = np.load(os.path.join(out, "H_1_0.npy"))
+    H2 = np.vstack([np.load(os.path.join(out, f"H_2_{r}.npy")) for r in range(2)])
+    assert H1.shape == H2.shape == (6000, 300)
+    assert np.abs(H1 - H2).max() <= H_RTOL * np.abs(H1).max()
+    np.testing.assert_allclose(np.load(os.path.join(out, "v_2_1.npy")), np.load(os.path.join(out, "v_1_0.npy")), rtol=EIG_RTOL)
