@@ -27,7 +27,8 @@ int tuning(const char *key, int dflt) {
 // ---- per-kernel HIP-event timing (off by default; bench.py switches it on) ----
 struct ProfRec { int name_id; hipEvent_t e0, e1; double work; };
 static std::mutex g_prof_mu;
-static bool g_prof_on = false;
+static int g_prof_on = 0;   // 0 off, 1 only the scopes named g_prof_only, 2 every scope
+static const char *const g_prof_only = "gemm_f64_kernel";
 static std::vector<std::string> g_prof_names;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<hipEvent_t> g_prof_pool;
@@ -42,6 +43,7 @@ static hipEvent_t prof_event() {
 int prof_begin(const char *name, hipStream_t st, double work) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
   if (!g_prof_on) return -1;
+  if (g_prof_on == 1 && strcmp(name, g_prof_only) != 0) return -1;
   int id = -1;
   for (size_t i = 0; i < g_prof_names.size(); ++i) if (g_prof_names[i] == name) { id = (int)i; break; }
   if (id < 0) { g_prof_names.push_back(name); id = (int)g_prof_names.size() - 1; }
@@ -63,7 +65,7 @@ using namespace flgp;
 
 extern "C" void flgp_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
-  g_prof_on = on != 0;
+  g_prof_on = on;
 }
 
 extern "C" void flgp_prof_reset(void) {

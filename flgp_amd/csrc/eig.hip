@@ -722,7 +722,7 @@ static int jacobi_refine(hipStream_t st, const double *T, int b, int K, EigWork 
                                (int)lds_small));
   const double tol_g = 4.0 * std::sqrt((double)g) * 1.1102230246251565e-16;
   hipLaunchKernelGGL(small_sym_eig_kernel<64>, dim3(1), dim3(1024), lds_small, st, T + (size_t)K * b + K, b, g, Vg,
-                     tol_g, 30);
+                     tol_g, tuning("eig_guard_sweeps", 3));
   FLGP_TRY(check_launch("small_sym_eig_kernel"));
   hipLaunchKernelGGL(embed_block_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, Vg, g, K, b, w.JV);
   FLGP_TRY(check_launch("embed_block_kernel"));
@@ -928,8 +928,8 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     // (a fixed small number of global sweeps alone is NOT enough, even late: the guard columns
     //  never converge, so their diagonal block of T stays dense -- measured: 2 sweeps put rmax
     //  back to 4e-2.  jacobi_refine diagonalises that block first, inside one workgroup.)
-    if (it < 2)         // bounds and a rough Ritz basis are all that is needed yet: loose threshold
-      FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps, -1, 1e10));
+    if (it < 2)         // bounds and a rough Ritz basis are all that is needed yet: loose threshold, capped sweeps
+      FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps, tuning(it == 0 ? "eig_sweeps_it0" : "eig_sweeps_it1", it == 0 ? 5 : -1), 1e10));
     else if (rmax_prev > 5e-2)
       FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps, -1, 1e6));
     else
