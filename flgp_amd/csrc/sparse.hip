@@ -168,21 +168,32 @@ __global__ __launch_bounds__(64) void gram_kernel(const int *__restrict__ ell_id
   const int sub = lane / r;         // which of the GR rows this lane serves
   const int a = lane - sub * r;     // slot inside the row
   const int p0 = colptr[j1], p1 = colptr[j1 + 1];
-  for (int pb = p0; pb < p1; pb += GR) {
-    const int p = pb + sub;
-    const bool act = (sub < GR) && (p < p1);
-    int j2 = 0;
-    double prod = 0.0;
-    if (act) {
-      const int e = pos[p];
-      const size_t rowbase = (size_t)(e / r) * r;
-      const double a1 = val[e];
-      j2 = ell_idx[rowbase + a];
-      prod = a1 * val[rowbase + a];
-    }
-    for (int q = 0; q < GR; ++q) {  // rows strictly in order; distinct j2 inside a row
-      if (act && sub == q) acc[j2] += prod;
-      __syncthreads();
+  // entry positions are fetched 64 at a time (one coalesced load), the rows of a step one step ahead of
+  // the LDS updates: the chain pos -> val/idx -> LDS is otherwise pure exposed latency
+  for (int pc = p0; pc < p1; pc += 64) {
+    const int epos = (pc + lane < p1) ? pos[pc + lane] : 0;
+    const int cnt = (p1 - pc < 64) ? p1 - pc : 64;
+    auto fetch = [&](int t, bool &act, int &j2, double &prod) {
+      const int slot = t * GR + sub;
+      act = (sub < GR) && (slot < cnt) && (t * GR < cnt);
+      const int e = __shfl(epos, (slot < 64) ? slot : 0, 64);
+      j2 = 0; prod = 0.0;
+      if (act) {
+        const size_t rowbase = (size_t)(e / r) * r;
+        j2 = ell_idx[rowbase + a];
+        prod = val[e] * val[rowbase + a];
+      }
+    };
+    const int nsteps = (cnt + GR - 1) / GR;
+    bool act, actn; int j2, j2n; double prod, prodn;
+    fetch(0, act, j2, prod);
+    for (int t = 0; t < nsteps; ++t) {
+      fetch(t + 1, actn, j2n, prodn);          // t + 1 == nsteps: all lanes inactive
+      for (int q = 0; q < GR; ++q) {           // rows strictly in order; distinct j2 inside a row
+        if (act && sub == q) acc[j2] += prod;
+        __syncthreads();
+      }
+      act = actn; j2 = j2n; prod = prodn;
     }
   }
   double *out = G + (size_t)j1 * ldg;
