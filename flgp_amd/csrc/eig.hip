@@ -647,7 +647,9 @@ static size_t eig_workspace_bytes(int s, int K) {
 // sweep_limit = k > 0: exactly k sweeps, a refinement step on an already nearly diagonal T.
 // JV is a product of plane rotations, i.e. orthogonal to rounding, however early the loop stops.
 static int jacobi_run(hipStream_t st, int b, EigWork &w, std::vector<double> &h_lam, int *sweeps_out,
-                      int sweep_limit, double tol_scale, bool strict) {
+                      int sweep_limit, double tol_scale, bool strict, double *JB = nullptr, double *JV = nullptr) {
+  if (!JB) JB = w.JB;
+  if (!JV) JV = w.JV;
   const JacobiPlan p = jacobi_plan(b);
   const void *kfn = p.nloc == 32 ? (const void *)jac_block_kernel<32>
                   : p.nloc == 16 ? (const void *)jac_block_kernel<16> : (const void *)jac_round_kernel;
@@ -663,13 +665,13 @@ static int jacobi_run(hipStream_t st, int b, EigWork &w, std::vector<double> &h_
   for (int sw = 0; sw < max_sweeps; ++sw) {
     for (int round = 0; round < p.nbc - 1; ++round) {
       if (p.nloc == 32)
-        hipLaunchKernelGGL(jac_block_kernel<32>, dim3(p.nbc / 2), dim3(1024), p.lds, st, w.JB, w.JV, b, b, p.nbc, round,
+        hipLaunchKernelGGL(jac_block_kernel<32>, dim3(p.nbc / 2), dim3(1024), p.lds, st, JB, JV, b, b, p.nbc, round,
                            tol, w.flags, tuning("jacobi_local_sweeps", 1));
       else if (p.nloc == 16)
-        hipLaunchKernelGGL(jac_block_kernel<16>, dim3(p.nbc / 2), dim3(1024), p.lds, st, w.JB, w.JV, b, b, p.nbc, round,
+        hipLaunchKernelGGL(jac_block_kernel<16>, dim3(p.nbc / 2), dim3(1024), p.lds, st, JB, JV, b, b, p.nbc, round,
                            tol, w.flags, tuning("jacobi_local_sweeps", 1));
       else
-        hipLaunchKernelGGL(jac_round_kernel, dim3(p.nbc / 2), dim3(p.nt), p.lds, st, w.JB, w.JV, b, b, p.w, p.nbc,
+        hipLaunchKernelGGL(jac_round_kernel, dim3(p.nbc / 2), dim3(p.nt), p.lds, st, JB, JV, b, b, p.w, p.nbc,
                            round, tol, w.flags, 1);
     }
     hipLaunchKernelGGL(jac_sweep_end_kernel, dim3(1), dim3(64), 0, st, w.flags);
@@ -680,7 +682,7 @@ static int jacobi_run(hipStream_t st, int b, EigWork &w, std::vector<double> &h_
       if (h_flags[1]) break;
     }
   }
-  hipLaunchKernelGGL(jac_values_kernel, dim3(b), dim3(256), 0, st, w.JB, w.JV, b, b, w.lam);
+  hipLaunchKernelGGL(jac_values_kernel, dim3(b), dim3(256), 0, st, JB, JV, b, b, w.lam);
   FLGP_TRY(check_launch("jac_values_kernel"));
   h_lam.resize(b);
   FLGP_HIP(hipMemcpyAsync(h_lam.data(), w.lam, sizeof(double) * b, hipMemcpyDeviceToHost, st));
@@ -713,17 +715,28 @@ static int jacobi_eig(hipStream_t st, const double *T, int ldt, int b, EigWork &
 static int jacobi_refine(hipStream_t st, const double *T, int b, int K, EigWork &w, std::vector<double> &h_lam,
                          int *sweeps_out, int sweeps) {
   const int g = b - K;
-  if (g < 2 || g > 64 || 2 * (size_t)g * g > (size_t)b * b)
+  if (g < 2 || 2 * (size_t)g * g > (size_t)b * b)
     return jacobi_eig(st, T, b, b, w, h_lam, sweeps_out, -1, 1.0);
   ProfScope ps("jacobi_refine", st, 8.0 * (double)b * b);
   double *Vg = w.X2;
-  const size_t lds_small = sizeof(double) * (4 * 64 * 64 + 2 * 64) + sizeof(int) * 64;
-  FLGP_HIP(hipFuncSetAttribute((const void *)small_sym_eig_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                               (int)lds_small));
-  const double tol_g = 4.0 * std::sqrt((double)g) * 1.1102230246251565e-16;
-  hipLaunchKernelGGL(small_sym_eig_kernel<64>, dim3(1), dim3(1024), lds_small, st, T + (size_t)K * b + K, b, g, Vg,
-                     tol_g, tuning("eig_guard_sweeps", 3));
-  FLGP_TRY(check_launch("small_sym_eig_kernel"));
+  if (g <= 64) {
+    const size_t lds_small = sizeof(double) * (4 * 64 * 64 + 2 * 64) + sizeof(int) * 64;
+    FLGP_HIP(hipFuncSetAttribute((const void *)small_sym_eig_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)lds_small));
+    const double tol_g = 4.0 * std::sqrt((double)g) * 1.1102230246251565e-16;
+    hipLaunchKernelGGL(small_sym_eig_kernel<64>, dim3(1), dim3(1024), lds_small, st, T + (size_t)K * b + K, b, g, Vg,
+                       tol_g, tuning("eig_guard_sweeps", 3));
+    FLGP_TRY(check_launch("small_sym_eig_kernel"));
+  } else {
+    // a guard block too large for one workgroup's LDS: the block Jacobi on the g x g matrix itself
+    // (its own B / V pair inside X2; a few sweeps are enough, the global sweeps below finish)
+    double *Bg = w.X2 + (size_t)g * g;
+    hipLaunchKernelGGL(jac_init_kernel, dim3(ceil_div((long)g * g, 256)), dim3(256), 0, st, T + (size_t)K * b + K, b, g,
+                       Bg, Vg, g, w.flags);
+    FLGP_TRY(check_launch("jac_init_kernel"));
+    std::vector<double> tmp;
+    FLGP_TRY(jacobi_run(st, g, w, tmp, nullptr, 4, 1.0, false, Bg, Vg));
+  }
   hipLaunchKernelGGL(embed_block_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, Vg, g, K, b, w.JV);
   FLGP_TRY(check_launch("embed_block_kernel"));
   // JB = T JV
