@@ -930,17 +930,32 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   bool converged = false;
   double *result = nullptr;
   double rmax_prev = 1.0;
+  const int rr_every = tuning("eig_rr_every", 3);
+  int since_rr = 0, it_meas = 0;
+  double rate = 0.1, rmax_meas = 0.0;
   for (it = 0; it < max_it; ++it) {
-    double *Z = F[0], *A = F[1], *B = F[2];
-    // ---- Rayleigh-Ritz on span(Q): Z = G Q, T = Q^T Z, T = W Th W^T
+    double *Z = F[0];
+    double *A, *B, *free1, *free2;     // Ritz vectors, G * Ritz vectors, two free s x b buffers
     FLGP_TRY(gemmG(Q, 1.0, 0.0, nullptr, 0.0, nullptr, Z));
     ++gprods;
+    // Rayleigh-Ritz may be skipped on some late iterations (rr_every > 1): the block is then used as it
+    // is (its columns are the previous Ritz vectors, filtered, cleaned and orthonormalised: still ordered
+    // and nearly Ritz), bounds are reused, and no convergence test is made on that iteration
+    // (rmax_prev is then advanced by the measured per-iteration contraction `rate`, so that the Rayleigh-
+    //  Ritz step and its convergence test land on the iteration where the tolerance is expected to be met)
+    const bool near_done = rmax_prev * rate <= 4.0 * tol;
+    const bool do_rr = !(rr_every > 1 && it >= 3 && rmax_prev < 1e-3 && since_rr + 1 < rr_every && !near_done);
+    double rmax = rmax_prev * rate, top = std::max(theta[0], 1e-300);
+    if (do_rr) {
+    since_rr = 0;
+    A = F[1]; B = F[2]; free1 = Q; free2 = Z;
+    // ---- Rayleigh-Ritz on span(Q): Z = G Q, T = Q^T Z, T = W Th W^T
     FLGP_TRY(gram_small(Q, Z, w.T));
     // T is far from diagonal only while the block is far from invariant: full Jacobi for the first
     // iterations, afterwards a single sweep refines the (already nearly diagonal) Ritz basis
     // (a fixed small number of global sweeps alone is NOT enough, even late: the guard columns
     //  never converge, so their diagonal block of T stays dense -- measured: 2 sweeps put rmax
-    //  back to 4e-2.  jacobi_refine diagonalises that block first, inside one workgroup.)
+    //  back to 4e-2.  jacobi_refine diagonalises that block first.)
     if (it < 2)         // bounds and a rough Ritz basis are all that is needed yet: loose threshold, capped sweeps
       FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps, tuning(it == 0 ? "eig_sweeps_it0" : "eig_sweeps_it1", it == 0 ? 5 : -1), 1e10));
     else if (rmax_prev > 5e-2)
@@ -957,14 +972,24 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     FLGP_TRY(check_launch("resid_kernel"));
     FLGP_HIP(hipMemcpyAsync(res.data(), w.res, sizeof(double) * K, hipMemcpyDeviceToHost, st));
     FLGP_HIP(hipStreamSynchronize(st));
-    double rmax = 0.0;
+    rmax = 0.0;
     for (int j = 0; j < K; ++j) rmax = std::max(rmax, res[j]);
-    const double top = std::max(theta[0], 1e-300);
+    top = std::max(theta[0], 1e-300);
     if (tuning("eig_verbose", 0))
       fprintf(stderr, "[flgp eig] it=%d gprods=%d theta0=%.15g thetaK=%.6g cut=%.6g rmax=%.3e cond=%.2e sweeps=%d\n",
               it, gprods, theta[0], theta[K - 1], theta[b - 1], rmax, cond, sweeps);
     if (rmax <= tol * top) { converged = true; result = A; break; }
+    if (it >= 3 && rmax_meas > 0.0 && rmax / top < rmax_meas) {
+      const double rt = std::pow((rmax / top) / rmax_meas, 1.0 / (double)(it - it_meas));
+      rate = std::min(0.5, std::max(0.02, rt));
+    }
+    rmax_meas = rmax / top; it_meas = it;
     rmax_prev = rmax / top;
+    } else {
+      ++since_rr;
+      A = Q; B = Z; free1 = F[1]; free2 = F[2];
+      rmax_prev *= rate;
+    }
 
     // ---- Chebyshev filter on [0, cut], scaled to 1 at the top Ritz value
     double cut = theta[b - 1];
@@ -981,8 +1006,8 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     double sigma = sigma1;
     // the Ritz vectors are needed again after the filter (see below): keep a copy
     FLGP_HIP(hipMemcpyAsync(w.Qold, A, sizeof(double) * (size_t)tot, hipMemcpyDeviceToDevice, st));
-    // degree 1: Y = (sigma1/e) (G A - c A) = (sigma1/e) (B - c A), into the free buffer Q
-    double *prev = A, *cur = Q, *next = Z;
+    // degree 1: Y = (sigma1/e) (G A - c A) = (sigma1/e) (B - c A), into a free buffer
+    double *prev = A, *cur = free1, *next = free2;
     hipLaunchKernelGGL(eig_axpby_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, st, sigma1 / e, B,
                        -sigma1 * c / e, A, cur, tot);
     FLGP_TRY(check_launch("eig_axpby_kernel"));
@@ -1003,7 +1028,8 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     FLGP_TRY(gram_small(w.Qold, cur, w.T));
     hipLaunchKernelGGL(mask_strict_upper_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, w.T, b);
     FLGP_TRY(check_launch("mask_strict_upper_kernel"));
-    FLGP_TRY(gemm_launch(st, s, b, b, -1.0, w.Qold, 1, s, w.T, 1, b, 1.0, cur, 1, s, cur, 1, s, nullptr, 0, 0.0, nullptr));
+    FLGP_TRY(gemm_launch(st, s, b, b, -1.0, w.Qold, 1, s, w.T, 1, b, 1.0, cur, 1, s, cur, 1, s, w.gemm_ws, w.gemm_ws_elems,
+                         0.0, nullptr));
     // ---- orthonormalise the filtered block (B is free by now; twice if ill-conditioned)
     FLGP_TRY(orth(cur, B, &cond));
     double *R = B;
@@ -1012,7 +1038,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
       R = prev;
     }
     // new roles: Q = R, the other three buffers are free
-    double *pool[4] = {A, Q, Z, B};
+    double *pool[4] = {A, B, free1, free2};
     int nf = 0;
     for (int q = 0; q < 4; ++q)
       if (pool[q] != R) F[nf++] = pool[q];
