@@ -777,7 +777,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   if (K < 0) K = s;
   FLGP_REQUIRE(K >= 1 && K <= s, "eig: need 1 <= K <= s (K=%d, s=%d)", K, s);
   FLGP_REQUIRE(work_bytes >= eig_workspace_bytes(s, K), "eig: workspace too small");
-  if (tol <= 0.0) tol = 1e-11;
+  if (tol <= 0.0) tol = 5e-11;   // relative residual of every wanted pair (Spectra's own tolerance is 1e-10)
   const bool dense = eig_use_dense(s, K);
   const int b = dense ? s : eig_block_size(s, K);
   FLGP_REQUIRE(!dense || s <= 4096, "eig: the full decomposition (K == s, or K close to s) is built for s <= 4096");
@@ -992,7 +992,8 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     }
 
     // ---- Chebyshev filter on [0, cut], scaled to 1 at the top Ritz value
-    double cut = theta[b - 1];
+    const int cut_pos = K + (b - K) * tuning("eig_cut_pct", 100) / 100;
+    double cut = theta[std::min(b - 1, std::max(K, cut_pos - 1))];
     if (!(cut > 0.0)) cut = 1e-3 * top;
     if (cut > 0.999 * top) cut = 0.999 * top;   // degenerate block: keep a valid interval
     const double e = 0.5 * cut, c = 0.5 * cut;
