@@ -72,4 +72,11 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
                 double *C, long c_is, long c_js, double *work, size_t work_elems, double gamma,
                 const double *E2);
 
+
+// Register-resident LAE kernels (lae_reg*.hip).  Returns FLGP_LAE_REG_NONE when no kernel of the family
+// is built for (r, d) and the caller falls through to the LDS kernels of lae.hip.
+#define FLGP_LAE_REG_NONE 1
+int launch_lae_reg(hipStream_t st, const double *dX, int n, int ldx, int d, const double *dUt, int dpad, int r,
+                   const int *d_knn, int ldk, int *d_ei, double *d_ev);
+
 }  // namespace flgp

@@ -944,7 +944,8 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     // (rmax_prev is then advanced by the measured per-iteration contraction `rate`, so that the Rayleigh-
     //  Ritz step and its convergence test land on the iteration where the tolerance is expected to be met)
     const bool near_done = rmax_prev * rate <= 4.0 * tol;
-    const bool do_rr = !(rr_every > 1 && it >= 3 && rmax_prev < 1e-3 && since_rr + 1 < rr_every && !near_done);
+    const bool early_skip = tuning("eig_skip_it1", 0) && it == 1;
+    const bool do_rr = !early_skip && !(rr_every > 1 && it >= 3 && rmax_prev < 1e-3 && since_rr + 1 < rr_every && !near_done);
     double rmax = rmax_prev * rate, top = std::max(theta[0], 1e-300);
     if (do_rr) {
     since_rr = 0;

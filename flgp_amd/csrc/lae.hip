@@ -14,57 +14,9 @@
 // bit for bit.  Output: for every point its r (anchor, weight) pairs sorted by anchor index,
 // i.e. the inner order of the reference's row-major Eigen::SparseMatrix == dgRMatrix slots.
 #include "common.h"
+#include "lae_dev.h"
 
 namespace flgp {
-
-// R > 0: compile-time r (everything unrolled, vectors in registers); R == 0: run-time r <= FLGP_RMAX.
-template <int R>
-struct LaeDims {
-  static constexpr int RR = R ? R : FLGP_RMAX;
-};
-
-// Euclidean projection onto the simplex (v_to_z_cpp, reference src/lae.cpp:137-153)
-template <int R>
-__device__ __forceinline__ void v_to_z_dev(const double *vv, double *zz, int r) {
-  constexpr int RR = LaeDims<R>::RR;
-  double vd[RR];
-#pragma unroll
-  for (int a = 0; a < RR; ++a) vd[a] = (a < r) ? vv[a] : -__builtin_inf();
-  // descending sort: odd-even transposition network (any correct sort gives the same array)
-#pragma unroll
-  for (int pass = 0; pass < RR; ++pass) {
-#pragma unroll
-    for (int a = pass & 1; a + 1 < RR; a += 2) {
-      const double hi = vd[a] < vd[a + 1] ? vd[a + 1] : vd[a];
-      const double lo = vd[a] < vd[a + 1] ? vd[a] : vd[a + 1];
-      vd[a] = hi;
-      vd[a + 1] = lo;
-    }
-  }
-  double cs[RR];
-  double c = 0.0;
-#pragma unroll
-  for (int a = 0; a < RR; ++a) {
-    c = (a == 0) ? vd[0] : c + vd[a];
-    cs[a] = c;
-  }
-  // rho = max{ j : v_(j) - (cumsum_j - 1)/j > 0 }; theta = (cumsum_rho - 1)/rho
-  double theta = (cs[0] - 1.0) / 1.0;
-#pragma unroll
-  for (int a = 1; a < RR; ++a) {
-    if (a < r) {
-      const double vstar = vd[a] - (cs[a] - 1.0) / (double)(a + 1);
-      if (vstar > 0) theta = (cs[a] - 1.0) / (double)(a + 1);
-    }
-  }
-#pragma unroll
-  for (int a = 0; a < RR; ++a) {
-    if (a < r) {
-      const double t = vv[a] - theta;
-      zz[a] = t > 0.0 ? t : 0.0;
-    }
-  }
-}
 
 __global__ void v_to_z_kernel(const double *__restrict__ v, int r, double *__restrict__ z) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
@@ -79,7 +31,7 @@ __global__ __launch_bounds__(64) void lae_kernel(const double *__restrict__ X, i
                                                  const double *__restrict__ Ut, int dpad, int r_rt,
                                                  const int *__restrict__ knn_idx, int ldk,
                                                  int *__restrict__ ell_idx, double *__restrict__ ell_val,
-                                                 int *__restrict__ iters_out, int NT) {
+                                                 int *__restrict__ iters_out, int NT, LaeMomentum mom) {
   // NT = lanes of the wave that own a point (64 unless the per-point LDS footprint forces fewer)
   constexpr int RR = LaeDims<R>::RR;
   const int r = R ? R : r_rt;
@@ -171,10 +123,10 @@ __global__ __launch_bounds__(64) void lae_kernel(const double *__restrict__ X, i
   const double z0 = 1.0 / (double)r;  // (src/lae.cpp:82)
 #pragma unroll
   for (int a = 0; a < RR; ++a) { zp[a] = z0; zc[a] = z0; v[a] = 0; grad[a] = 0; vt[a] = 0; z[a] = 0; dz[a] = 0; }
-  double dp = 0.0, dc = 1.0, bc = 1.0;  // (:83-84)
+  int be = 0;  // beta_curr = 2^be (:83-84)
   int t = 0;
   for (; t < 100; ++t) {                // T = 100 (:86)
-    const double alpha = (dp - 1.0) / dc;  // (:99)
+    const double alpha = mom.alpha[t];  // (:99)
 #pragma unroll
     for (int a = 0; a < RR; ++a) v[a] = zc[a] + alpha * (zc[a] - zp[a]);  // (:101)
     const double g_v = half_sq_resid(v);                                  // (:103)
@@ -189,8 +141,8 @@ __global__ __launch_bounds__(64) void lae_kernel(const double *__restrict__ X, i
       }
     }
     for (int j = 0;; ++j) {  // backtracking (:107-129); capped at 64 doublings as the oracle
-      const double beta = __builtin_ldexp(bc, j);  // std::pow(2,j)*beta_curr (:110), exact
-      const double ib = 1.0 / beta;
+      const double beta = pow2(be + j);  // std::pow(2,j)*beta_curr (:110), exact
+      const double ib = inv_pow2(be + j);
 #pragma unroll
       for (int a = 0; a < RR; ++a) vt[a] = v[a] - ib * grad[a];  // (:112)
       v_to_z(vt, z);                                             // (:114)
@@ -206,14 +158,12 @@ __global__ __launch_bounds__(64) void lae_kernel(const double *__restrict__ X, i
       }
       const double g_t = (g_v + gd) + (beta * sq) / 2.0;  // (:117)
       if (g_z <= g_t || j >= 64) {
-        bc = beta;
+        be += j;
 #pragma unroll
         for (int a = 0; a < RR; ++a) { zp[a] = zc[a]; zc[a] = z[a]; }
         break;
       }
     }
-    dp = dc;  // (:127-128)
-    dc = (1.0 + __builtin_sqrt(1.0 + (4.0 * dc) * dc)) / 2.0;
     double sq = 0.0;
 #pragma unroll
     for (int a = 0; a < RR; ++a) {
@@ -290,7 +240,7 @@ static int launch_lae(hipStream_t st, const double *dX, int n, int ldx, int d, c
   if (lds > 48 * 1024)
     FLGP_HIP(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, st, dX, n, ldx, d, dUt, dpad, r, d_knn, ldk, d_ei, d_ev,
-                     d_iters, nt);
+                     d_iters, nt, lae_momentum());
   return check_launch("lae_kernel");
 }
 
@@ -308,6 +258,11 @@ extern "C" int flgp_dev_lae(void *stream, const double *dX, int n, int ldx, int 
   if (n == 0) return FLGP_OK;
   int *it = nullptr;
 #define LAE_ARGS st, dX, n, ldx, d, dUt, dpad, r, d_knn_idx, ldk, d_ell_idx, d_ell_val, it
+  if (tuning("lae_variant", 1) == 1) {
+    // register-resident kernels (lae_reg.h) where r x d/lanes fits the VGPR file; LDS kernels otherwise
+    const int rc = launch_lae_reg(st, dX, n, ldx, d, dUt, dpad, r, d_knn_idx, ldk, d_ell_idx, d_ell_val);
+    if (rc != FLGP_LAE_REG_NONE) return rc;
+  }
   switch (r) {
     case 1: return launch_lae<1, true>(LAE_ARGS);
     case 2: return launch_lae<2, true>(LAE_ARGS);

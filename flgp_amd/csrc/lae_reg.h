@@ -1,0 +1,246 @@
+// Register-resident Local Anchor Embedding kernels.
+//
+// lae_kernel (lae.hip) keeps each point's r gathered anchors in LDS; every residual evaluation then
+// streams r*d doubles through the LDS pipe, which feeds one wave-wide 8-byte read per 4 clocks per CU
+// while the four SIMDs could retire four fp64 FMAs in the same time -- and for r*d >= 160 the 80+ KB per
+// wave leave two waves (or fewer lanes) per CU.  Here the anchors live in VGPRs: LP lanes share one
+// point, lane `sub` holding coordinates [sub*DPL, (sub+1)*DPL) of all r anchors (R x DPL doubles), so
+// the r x d products of a residual evaluation touch no memory.  Only the packed Gram block (LDS, one copy
+// per point) and the point itself (LDS) are read from memory inside the iteration.
+//
+// Arithmetic is the oracle's, operation for operation (local_anchor_embedding_cpp, reference
+// src/lae.cpp:83-132): every k-ascending FMA chain that crosses lanes is continued in coordinate order --
+// lane 0 runs its DPL terms, hands the partial sum to lane 1 by DPP quad-permute, and so on; all lanes of
+// a group execute every leg and keep the leg owner's result, so the r-vectors stay replicated bit for
+// bit and the simplex projection / line search need no further exchange.
+#pragma once
+#include "common.h"
+#include "lae_dev.h"
+
+namespace flgp {
+
+// broadcast the value held by lane `j` of each LP-lane group to the whole group (LP in {1, 2, 4})
+template <int CTRL>
+__device__ __forceinline__ double dpp_quad(double v) {
+  int lo = __double2loint(v), hi = __double2hiint(v);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xf, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xf, 0xf, false);
+  return __hiloint2double(hi, lo);
+}
+template <int LP>
+__device__ __forceinline__ double group_bcast(double v, int j) {
+  if constexpr (LP == 1) {
+    return v;
+  } else if constexpr (LP == 2) {
+    return j == 0 ? dpp_quad<0xA0>(v) : dpp_quad<0xF5>(v);          // quad_perm [0,0,2,2] / [1,1,3,3]
+  } else {
+    static_assert(LP == 4, "LP must be 1, 2 or 4");
+    switch (j) {
+      case 0: return dpp_quad<0x00>(v);
+      case 1: return dpp_quad<0x55>(v);
+      case 2: return dpp_quad<0xAA>(v);
+      default: return dpp_quad<0xFF>(v);
+    }
+  }
+}
+
+template <int R, int DPL, int LP>
+__global__ __launch_bounds__(64) void lae_reg_kernel(const double *__restrict__ X, int n, int ldx, int d,
+                                                     const double *__restrict__ Ut, int dpad,
+                                                     const int *__restrict__ knn_idx, int ldk,
+                                                     int *__restrict__ ell_idx, double *__restrict__ ell_val,
+                                                     LaeMomentum mom) {
+  constexpr int PTS = 64 / LP;
+  constexpr int NG = R * (R + 1) / 2;
+  __shared__ double Gl[NG * PTS];    // packed upper triangle of U_i U_i^T, [e][point]
+  __shared__ double Xl[DPL * 64];    // this lane's slice of the point, [k][lane]
+  const int tid = threadIdx.x;
+  const int sub = tid & (LP - 1), pl = tid / LP;
+  const int kb = sub * DPL;
+  long i = (long)blockIdx.x * PTS + pl;
+  const bool live = i < n;
+  if (!live) i = n - 1;
+  int id[R];
+#pragma unroll
+  for (int a = 0; a < R; ++a) id[a] = knn_idx[(size_t)a * ldk + i];
+  double u[R][DPL];
+#pragma unroll
+  for (int a = 0; a < R; ++a)
+#pragma unroll
+    for (int k = 0; k < DPL; ++k) u[a][k] = (kb + k < d) ? Ut[(size_t)id[a] * dpad + kb + k] : 0.0;
+#pragma unroll
+  for (int k = 0; k < DPL; ++k) Xl[k * 64 + tid] = (kb + k < d) ? X[(size_t)(kb + k) * ldx + i] : 0.0;
+
+  // sum_k p(k) q(k) over all coordinates as ONE k-ascending chain (first term a product, the rest FMAs),
+  // continued lane to lane.  Coordinates k >= d are zero in both operands: fma(0, 0, acc) returns acc
+  // (up to the sign of a zero, which no comparison or non-zero value downstream can see), so the padded
+  // chain ends on the oracle's d-term value.
+  auto chain = [&](auto term) -> double {
+    double acc = 0.0;
+#pragma unroll
+    for (int j = 0; j < LP; ++j) {
+      double t = acc;
+#pragma unroll
+      for (int k = 0; k < DPL; ++k) {
+        double p, q;
+        term(k, p, q);
+        t = (j == 0 && k == 0) ? p * q : __builtin_fma(p, q, t);
+      }
+      acc = group_bcast<LP>(t, j);
+    }
+    return acc;
+  };
+
+  // UUt (src/lae.cpp:90) and x*Ut
+  double xUt[R];
+  {
+    int e = 0;
+#pragma unroll
+    for (int a = 0; a < R; ++a) {
+      xUt[a] = chain([&](int k, double &p, double &q) { p = Xl[k * 64 + tid]; q = u[a][k]; });
+#pragma unroll
+      for (int b = a; b < R; ++b, ++e) {
+        const double g = chain([&](int k, double &p, double &q) { p = u[a][k]; q = u[b][k]; });
+        if (sub == 0) Gl[e * PTS + pl] = g;
+      }
+    }
+  }
+  // (each wave is its own workgroup and LDS operations of one wave complete in order: no barrier needed)
+  auto Gab = [&](int a, int b) -> double {
+    const int lo = a < b ? a : b, hi = a < b ? b : a;
+    return Gl[(lo * R - lo * (lo - 1) / 2 + (hi - lo)) * PTS + pl];
+  };
+  auto half_sq_resid = [&](const double *zz) -> double {
+    if constexpr (LP == 1) {
+      double acc = 0.0;
+#pragma unroll
+      for (int k = 0; k < DPL; ++k) {
+        double zu = zz[0] * u[0][k];
+#pragma unroll
+        for (int a = 1; a < R; ++a) zu = __builtin_fma(zz[a], u[a][k], zu);
+        const double df = Xl[k * 64 + tid] - zu;
+        acc = (k == 0) ? df * df : __builtin_fma(df, df, acc);
+      }
+      return acc / 2.0;
+    } else {
+      double df[DPL];
+#pragma unroll
+      for (int k = 0; k < DPL; ++k) {
+        double zu = zz[0] * u[0][k];
+#pragma unroll
+        for (int a = 1; a < R; ++a) zu = __builtin_fma(zz[a], u[a][k], zu);
+        df[k] = Xl[k * 64 + tid] - zu;
+      }
+      return chain([&](int k, double &p, double &q) { p = df[k]; q = df[k]; }) / 2.0;
+    }
+  };
+
+  double zp[R], zc[R], v[R], grad[R], z[R];
+  const double z0 = 1.0 / (double)R;
+#pragma unroll
+  for (int a = 0; a < R; ++a) { zp[a] = z0; zc[a] = z0; }
+  int be = 0;  // beta_curr = 2^be
+  for (int t = 0; t < 100; ++t) {
+    const double alpha = mom.alpha[t];
+#pragma unroll
+    for (int a = 0; a < R; ++a) v[a] = zc[a] + alpha * (zc[a] - zp[a]);
+    const double g_v = half_sq_resid(v);
+#pragma unroll
+    for (int a = 0; a < R; ++a) {
+      double acc = v[0] * Gab(0, a);
+#pragma unroll
+      for (int b = 1; b < R; ++b) acc = __builtin_fma(v[b], Gab(b, a), acc);
+      grad[a] = acc - xUt[a];
+    }
+    for (int j = 0;; ++j) {
+      const double beta = pow2(be + j);
+      const double ib = inv_pow2(be + j);
+      double vt[R];
+#pragma unroll
+      for (int a = 0; a < R; ++a) vt[a] = v[a] - ib * grad[a];
+      v_to_z_dev<R>(vt, z, R);
+      const double g_z = half_sq_resid(z);
+      double gd = 0.0, sq = 0.0;
+#pragma unroll
+      for (int a = 0; a < R; ++a) {
+        const double dz = z[a] - v[a];
+        gd = (a == 0) ? grad[0] * dz : __builtin_fma(grad[a], dz, gd);
+        sq = (a == 0) ? dz * dz : __builtin_fma(dz, dz, sq);
+      }
+      const double g_t = (g_v + gd) + (beta * sq) / 2.0;
+      if (g_z <= g_t || j >= 64) {
+        be += j;
+#pragma unroll
+        for (int a = 0; a < R; ++a) { zp[a] = zc[a]; zc[a] = z[a]; }
+        break;
+      }
+    }
+    double sq = 0.0;
+#pragma unroll
+    for (int a = 0; a < R; ++a) {
+      const double df = zc[a] - zp[a];
+      sq = (a == 0) ? df * df : __builtin_fma(df, df, sq);
+    }
+    if (sq < 1e-5) break;
+  }
+  // ELL row sorted by anchor index (what the CSR conversion of the reference produces)
+  int key[R];
+#pragma unroll
+  for (int a = 0; a < R; ++a) key[a] = id[a];
+#pragma unroll
+  for (int pass = 0; pass < R; ++pass) {
+#pragma unroll
+    for (int a = pass & 1; a + 1 < R; a += 2) {
+      const bool sw = key[a + 1] < key[a];
+      const int k0 = sw ? key[a + 1] : key[a], k1 = sw ? key[a] : key[a + 1];
+      const double w0 = sw ? zc[a + 1] : zc[a], w1 = sw ? zc[a] : zc[a + 1];
+      key[a] = k0; key[a + 1] = k1; zc[a] = w0; zc[a + 1] = w1;
+    }
+  }
+  if (live && sub == 0) {
+#pragma unroll
+    for (int a = 0; a < R; ++a) {
+      ell_idx[(size_t)i * R + a] = key[a];
+      ell_val[(size_t)i * R + a] = zc[a];
+    }
+  }
+}
+
+#define FLGP_LAE_REG_ARGS                                                                                      \
+  hipStream_t st, const double *dX, int n, int ldx, int d, const double *dUt, int dpad, const int *d_knn, int ldk, \
+      int *d_ei, double *d_ev
+
+template <int R, int DPL, int LP>
+int launch_lae_reg_t(FLGP_LAE_REG_ARGS) {
+  ProfScope ps("lae_kernel", st, 8.0 * (double)n * R);
+  hipLaunchKernelGGL((lae_reg_kernel<R, DPL, LP>), dim3(ceil_div(n, 64 / LP)), dim3(64), 0, st, dX, n, ldx, d, dUt,
+                     dpad, d_knn, ldk, d_ei, d_ev, lae_momentum());
+  return check_launch("lae_reg_kernel");
+}
+
+#define FLGP_LAE_REG_PASS st, dX, n, ldx, d, dUt, dpad, d_knn, ldk, d_ei, d_ev
+
+// Kernels built for a compile-time r.  One lane per point on the narrowest slice that holds d; once
+// R x 16 doubles no longer fit the 256 architectural VGPRs (R >= 9: the rest would sit in AGPRs behind
+// two v_accvgpr_read per operand) two lanes share a point.  Measured on 1e6 points, r = 10, d = 16:
+// 16x1 3.0 ms, 8x2 2.6 ms, 4x4 4.0 ms; LDS-resident kernel 8.5 ms (scripts/exp_lae.py).
+template <int R>
+int launch_lae_reg_r(FLGP_LAE_REG_ARGS, int force_dpl, int force_lp) {
+  if (force_dpl == 4 && force_lp == 4 && d <= 16) return launch_lae_reg_t<R, 4, 4>(FLGP_LAE_REG_PASS);
+  if (force_dpl == 8 && force_lp == 4 && d <= 32) return launch_lae_reg_t<R, 8, 4>(FLGP_LAE_REG_PASS);
+  if (force_dpl == 8 && force_lp == 2 && d <= 16) return launch_lae_reg_t<R, 8, 2>(FLGP_LAE_REG_PASS);
+  if (d <= 4) return launch_lae_reg_t<R, 4, 1>(FLGP_LAE_REG_PASS);
+  if (d <= 8) return launch_lae_reg_t<R, 8, 1>(FLGP_LAE_REG_PASS);
+  if constexpr (R <= 10) {
+    if (d <= 16 && (R <= 8 || force_dpl == 16)) return launch_lae_reg_t<R, 16, 1>(FLGP_LAE_REG_PASS);
+    if (d <= 16) return launch_lae_reg_t<R, 8, 2>(FLGP_LAE_REG_PASS);
+    if (d <= 32) return launch_lae_reg_t<R, 16, 2>(FLGP_LAE_REG_PASS);
+    if (d <= 64) return launch_lae_reg_t<R, 16, 4>(FLGP_LAE_REG_PASS);
+  } else {
+    if (d <= 16) return launch_lae_reg_t<R, 8, 2>(FLGP_LAE_REG_PASS);
+    if (d <= 32) return launch_lae_reg_t<R, 8, 4>(FLGP_LAE_REG_PASS);
+  }
+  return FLGP_LAE_REG_NONE;
+}
+
+}  // namespace flgp

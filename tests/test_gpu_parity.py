@@ -92,7 +92,8 @@ def test_v_to_z(oracle):
         np.testing.assert_array_equal(api.v_to_z_cpp(v).ravel(), oracle.v_to_z(v))
 
 
-@pytest.mark.parametrize("r,d", [(1, 2), (2, 2), (3, 2), (5, 3), (8, 16), (10, 16), (12, 4), (16, 3), (20, 2), (10, 64)])
+@pytest.mark.parametrize("r,d", [(1, 2), (2, 2), (3, 2), (5, 3), (8, 16), (10, 16), (12, 4), (16, 3), (20, 2), (10, 64),
+                                 (10, 12), (10, 17), (10, 32), (10, 40), (7, 16), (9, 33), (13, 8), (16, 16), (14, 30)])
 def test_lae_bit_exact(oracle, r, d):
     n, s = 500, 64
     X, U0, _ = make_case(n, d, s, r, seed=31 * r + d, with_sizes=False)
@@ -102,6 +103,19 @@ def test_lae_bit_exact(oracle, r, d):
     np.testing.assert_array_equal(Z.indices.reshape(n, r), ei)
     np.testing.assert_array_equal(Z.data.reshape(n, r), ev)      # bit for bit
     assert (ev >= 0).all() and np.abs(ev.sum(1) - 1).max() < 1e-13
+
+
+def test_lae_huge_coordinates(oracle):
+    # coordinates ~1e140: the simplex projection sees entries beyond 2^900 and must take the IEEE-division
+    # branch (lae_dev.h) -- still bit for bit
+    n, d, s, r = 300, 16, 40, 10
+    X, U0, _ = make_case(n, d, s, r, seed=77, with_sizes=False)
+    X = X * 1e140; U0 = U0 * 1e140
+    Z = api.LAE_cpp(X, U0, r)
+    ei, ev = oracle.lae(X, U0, r)
+    assert np.isfinite(ev).all()
+    np.testing.assert_array_equal(Z.indices.reshape(n, r), ei)
+    np.testing.assert_array_equal(Z.data.reshape(n, r), ev)
 
 
 def test_lae_slow_converging_points(oracle):

@@ -1,4 +1,6 @@
 """CPU: host-side logic of the package (synthetic generators, sharding arithmetic, CSR plumbing)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -51,3 +53,15 @@ def test_csr_plumbing_rejects_ragged_rows():
     assert (n, s, r) == (2, 3, 2)
     np.testing.assert_array_equal(j, [0, 2, 1, 2])        # sorted within rows, as dgRMatrix
     np.testing.assert_array_equal(x, [2.0, 1.0, 3.0, 4.0])
+
+
+def test_constant_division_identity(tmp_path):
+    """(cumsum - 1)/j in the LAE kernels is three FMA-class operations instead of an IEEE division
+    (flgp_amd/csrc/lae_dev.h div_const); the identity is checked here on the host's IEEE arithmetic."""
+    import subprocess
+    src = os.path.join(os.path.dirname(__file__), "c", "div_const_check.c")
+    exe = str(tmp_path / "div_const_check")
+    subprocess.run(["gcc", "-O2", "-mfma", "-ffp-contract=off", src, "-o", exe, "-lm"], check=True)
+    out = subprocess.run([exe, "1000000"], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout
+    assert "mismatches 0" in out.stdout
