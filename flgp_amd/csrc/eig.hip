@@ -220,16 +220,20 @@ typedef double jd4 __attribute__((ext_vector_type(4)));
 template <int NLOC>
 __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B, double *__restrict__ V, int b,
                                                          int ldb, int nbc, int round, double tol,
-                                                         int *__restrict__ flags, int local_sweeps) {
+                                                         int *__restrict__ flags, int local_sweeps,
+                                                         int cross_only) {
   constexpr int WB = NLOC / 2;        // block-column width
   constexpr int NP = NLOC / 2;        // pairs per local round
   constexpr int NT16 = NLOC / 16;     // 16-wide tiles per side
   constexpr int TILES = NT16 * NT16;
   constexpr int KP = 4;               // row parts of the Gram product
   extern __shared__ double sm[];
-  __shared__ int any_rot;
+  __shared__ int any_rot, visit_rot;
+  __shared__ int round_rot[3];
   if (flags[1]) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 3) round_rot[tid] = 0;
+  if (tid == 0) visit_rot = 0;
   int I, J;
   rr_pair(nbc, round, blockIdx.x, I, J);
   const int cI = I * WB, cJ = J * WB;
@@ -320,10 +324,15 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
     if (tid == 0) any_rot = 0;
     __syncthreads();
     int rot_here = 0;
-    for (int rr = 0; rr < NLOC - 1; ++rr) {
+    // cross_only: only the WB x WB pairs (p in block column I, q in block column J) are visited, in WB
+    // rounds; the pairs inside a block column are left to the one visit per sweep that runs the full
+    // round-robin (jacobi_run: round 0), so a sweep rotates every pair of the b columns exactly once
+    const int nrounds = cross_only ? NP : NLOC - 1;
+    for (int rr = 0; rr < nrounds; ++rr) {
       if (tid < NP) {
         int p, q;
-        rr_pair(NLOC, rr, tid, p, q);
+        if (cross_only) { p = tid; q = NP + ((tid + rr) & (NP - 1)); }
+        else rr_pair(NLOC, rr, tid, p, q);
         const double al = Gc[p * NLOC + p], be = Gc[q * NLOC + q], ga = Gc[p * NLOC + q];
         double cs = 1.0, sn = 0.0;
         if (ga * ga > tol2 * (al * be) && al > 0.0 && be > 0.0) {
@@ -334,11 +343,14 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
           cs = x2 * r2;
           sn = (dl >= 0.0 ? ga : -ga) * (r1 * r2);
           ++rot_here;
+          round_rot[rr % 3] = 1;
         }
         cc[p] = cs; dd[p] = -sn; pr[p] = q;   // new_p = c old_p - s old_q
         cc[q] = cs; dd[q] = sn;  pr[q] = p;   // new_q = s old_p + c old_q
       }
+      if (tid == 0) round_rot[(rr + 2) % 3] = 0;   // last read two barriers ago, next set two barriers on
       __syncthreads();
+      if (!round_rot[rr % 3]) continue;            // nobody rotates: both buffers stay as they are
       for (int e = tid; e < NLOC * NLOC; e += 1024) {
         const int i = e / NLOC, j = e % NLOC;
         const int pi = pr[i], pj = pr[j];
@@ -351,11 +363,13 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
       double *t2 = Wc; Wc = Wn; Wn = t2;
     }
     rotations += rot_here;
-    if (rot_here) any_rot = 1;
+    if (rot_here) { any_rot = 1; visit_rot = 1; }
     __syncthreads();
     if (!any_rot) break;
     __syncthreads();
   }
+  __syncthreads();
+  if (!visit_rot) return;   // the NLOC columns were orthogonal to the threshold already: panels untouched
   if (Wc != Wm) {   // an odd number of rounds ran: move the result where apply_w reads it
     for (int e = tid; e < NLOC * NLOC; e += 1024) Wm[e] = Wc[e];
   }
@@ -383,10 +397,12 @@ __global__ __launch_bounds__(1024) void small_sym_eig_kernel(const double *__res
   constexpr int NP = N / 2;
   extern __shared__ double sm[];
   __shared__ int any_rot;
+  __shared__ int round_rot[3];
   double *Gc = sm, *Gn = sm + N * N, *Wc = sm + 2 * N * N, *Wn = sm + 3 * N * N;
   double *cc = sm + 4 * N * N, *dd = cc + N;
   int *pr = (int *)(dd + N);
   const int tid = threadIdx.x;
+  if (tid < 3) round_rot[tid] = 0;
   for (int e = tid; e < N * N; e += 1024) {
     const int i = e / N, j = e % N;
     Gc[e] = (i < g && j < g) ? 0.5 * (T[(size_t)j * ldt + i] + T[(size_t)i * ldt + j]) : 0.0;
@@ -412,11 +428,14 @@ __global__ __launch_bounds__(1024) void small_sym_eig_kernel(const double *__res
           cs = x2 * r2;
           sn = (dl >= 0.0 ? ga : -ga) * (r1 * r2);
           ++rot_here;
+          round_rot[rr % 3] = 1;
         }
         cc[p] = cs; dd[p] = -sn; pr[p] = q;
         cc[q] = cs; dd[q] = sn;  pr[q] = p;
       }
+      if (tid == 0) round_rot[(rr + 2) % 3] = 0;
       __syncthreads();
+      if (!round_rot[rr % 3]) continue;
       for (int e = tid; e < N * N; e += 1024) {
         const int i = e / N, j = e % N;
         const int pi = pr[i], pj = pr[j];
@@ -662,14 +681,16 @@ static int jacobi_run(hipStream_t st, int b, EigWork &w, std::vector<double> &h_
   // rounding noise, so a tighter threshold only chases noise (cf. LAPACK dgesvj: sqrt(m) eps)
   const double tol = tol_scale * 4.0 * std::sqrt((double)b) * 1.1102230246251565e-16;
   int h_flags[4] = {0, 0, 0, 0};
+  const int cross_from = tuning("jacobi_cross_from", 0);   // 1000 = never
   for (int sw = 0; sw < max_sweeps; ++sw) {
     for (int round = 0; round < p.nbc - 1; ++round) {
+      const int cross = (round > 0 && sw >= cross_from) ? 1 : 0;
       if (p.nloc == 32)
         hipLaunchKernelGGL(jac_block_kernel<32>, dim3(p.nbc / 2), dim3(1024), p.lds, st, JB, JV, b, b, p.nbc, round,
-                           tol, w.flags, tuning("jacobi_local_sweeps", 1));
+                           tol, w.flags, tuning("jacobi_local_sweeps", 1), cross);
       else if (p.nloc == 16)
         hipLaunchKernelGGL(jac_block_kernel<16>, dim3(p.nbc / 2), dim3(1024), p.lds, st, JB, JV, b, b, p.nbc, round,
-                           tol, w.flags, tuning("jacobi_local_sweeps", 1));
+                           tol, w.flags, tuning("jacobi_local_sweeps", 1), cross);
       else
         hipLaunchKernelGGL(jac_round_kernel, dim3(p.nbc / 2), dim3(p.nt), p.lds, st, JB, JV, b, b, p.w, p.nbc,
                            round, tol, w.flags, 1);
