@@ -916,6 +916,59 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
       hipLaunchKernelGGL(sym_scale_apply_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, w.T, b, w.dinv);
       FLGP_TRY(check_launch("sym_scale_kernel"));
     }
+    if (tuning("eig_ns_scaled", 1)) {
+      // ill-conditioned block (the first filters amplify by 1e3 and leave cond(S) ~ 1e5): the same
+      // Newton-Schulz iteration on S / sigma with sigma >= lambda_max.  Every eigenvalue x of Z Y obeys
+      // x <- x (3 - x)^2 / 4, which maps (0, 3) into (0, 1] and lifts a small x by 9/4 per step until
+      // the quadratic phase: ~log(cond)/log(2.25) + 5 iterations of three b x b GEMMs, against twenty
+      // Jacobi sweeps.  sigma = |S^2|_F^(1/2) over-estimates lambda_max by at most b^(1/4).
+      double *Yc = w.T, *Zc = w.JV, *Mm = w.W, *Yn = w.JB, *Zn = w.X2;
+      FLGP_TRY(small_gemm(Yc, Yc, 1.0, 0.0, nullptr, Yn));
+      hipLaunchKernelGGL(eig_axpby_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, 1.0, Yn, 1.0, w.Id, Mm,
+                         (long)b * b);   // Mm = S^2 + I, so that the distance-to-identity kernel returns |S^2|_F
+      FLGP_TRY(check_launch("eig_axpby_kernel"));
+      double f2 = 0.0;
+      FLGP_TRY(dist_to_identity(Mm, &f2));
+      const double sigma = 1.02 * std::sqrt(f2);
+      if (sigma > 0.0 && std::isfinite(sigma)) {
+        hipLaunchKernelGGL(eig_axpby_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, 1.0 / sigma, Yc, 0.0, w.Id,
+                           Yn, (long)b * b);
+        FLGP_TRY(check_launch("eig_axpby_kernel"));
+        std::swap(Yc, Yn);
+        FLGP_HIP(hipMemcpyAsync(Zc, w.Id, sizeof(double) * (size_t)b * b, hipMemcpyDeviceToDevice, st));
+        double dm = 1.0;
+        bool ok = false;
+        for (int k = 0; k < 72 && !ok; ++k) {
+          FLGP_TRY(small_gemm(Zc, Yc, -0.5, 1.5, w.Id, Mm));
+          FLGP_TRY(small_gemm(Yc, Mm, 1.0, 0.0, nullptr, Yn));
+          FLGP_TRY(small_gemm(Mm, Zc, 1.0, 0.0, nullptr, Zn));
+          std::swap(Yc, Yn);
+          std::swap(Zc, Zn);
+          if (k >= 8 && k % 3 == 2) {
+            FLGP_TRY(dist_to_identity(Mm, &dm));
+            if (!std::isfinite(dm)) break;
+            ok = dm < 1e-9;
+          }
+        }
+        if (ok) {
+          double zn = 0.0;   // |Z - I|_F^2 + 1 >= 1/x_min: an upper bound of cond(S / sigma)
+          FLGP_TRY(dist_to_identity(Zc, &zn));
+          hipLaunchKernelGGL(eig_axpby_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, 1.0 / std::sqrt(sigma),
+                             Zc, 0.0, w.Id, Zn, (long)b * b);
+          hipLaunchKernelGGL(row_scale_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, Zn, b, w.dinv, w.W);
+          FLGP_TRY(check_launch("row_scale_kernel"));
+          if (cond_out) {
+            *cond_out = 1.0 + zn * zn;
+            if (dm > 1e-12) *cond_out = std::max(*cond_out, 2e8);   // ask for the second pass
+          }
+          ++ns_orths;
+          return rotate(Yin, w.W, Qout);
+        }
+      }
+      FLGP_TRY(gram_small(Yin, Yin, w.T));
+      hipLaunchKernelGGL(sym_scale_apply_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, w.T, b, w.dinv);
+      FLGP_TRY(check_launch("sym_scale_kernel"));
+    }
     ++jac_orths;
     FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps));
     double lmax = 0.0;
