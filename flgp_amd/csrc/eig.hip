@@ -387,6 +387,52 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
   store_panel(V);
 }
 
+// ------------------------------------------------------------------------------------------
+// b x b x b products of the orthonormalisation (Newton-Schulz: three per iteration, hundreds per
+// solve).  The tiled GEMM of gemm.hip needs split-K and a reduction launch to find 33 MFLOP of
+// parallelism in four 128 x 128 tiles (14 + 9 us); here every 16 x 16 tile of C is one wave, operands go
+// straight from L2 into the MFMA operand layout (no LDS, no reduction):
+//   C = alpha A B + beta E   (all b x b, column-major, leading dimension b; b % 16 == 0)
+// Lane l = (r = l & 15, kq = l >> 4) owns the contiguous k range [kq b/4, (kq+1) b/4): step t feeds
+// A(i0 + r, kq b/4 + t) and B(kq b/4 + t, j0 + r) -- a permutation of the k index, the same for both
+// operands.  Up to two independent products per launch (blockIdx.z).
+// ------------------------------------------------------------------------------------------
+struct SmallGemm {
+  const double *A, *B, *E;
+  double *C;
+  double alpha, beta;
+};
+struct SmallGemmPair {
+  SmallGemm g[2];
+};
+
+__global__ __launch_bounds__(64) void small_gemm_kernel(SmallGemmPair args, int b) {
+  const SmallGemm g = args.g[blockIdx.z];
+  const int lane = threadIdx.x, r = lane & 15, kq = lane >> 4;
+  const int i0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
+  const int kn = b >> 2;
+  const double *pa = g.A + (size_t)(kq * kn) * b + i0 + r;      // A(i0 + r, kq kn + t): stride b in t
+  const double *pb = g.B + (size_t)(j0 + r) * b + kq * kn;      // B(kq kn + t, j0 + r): contiguous in t
+  jd4 acc = jd4{0.0, 0.0, 0.0, 0.0};
+  int t = 0;
+  for (; t + 8 <= kn; t += 8) {
+    double av[8], bv[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { av[u] = pa[(size_t)(t + u) * b]; bv[u] = pb[t + u]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+  }
+  for (; t < kn; ++t) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[(size_t)t * b], pb[t], acc, 0, 0, 0);
+  // D(row = kq + 4 reg, col = r)
+#pragma unroll
+  for (int reg = 0; reg < 4; ++reg) {
+    const size_t e = (size_t)(j0 + r) * b + i0 + kq + 4 * reg;
+    double v = g.alpha * acc[reg];
+    if (g.E) v += g.beta * g.E[e];
+    g.C[e] = v;
+  }
+}
+
 // Symmetric eigendecomposition of a small matrix (g <= N) by one workgroup: classical two-sided
 // cyclic Jacobi, the whole matrix and the rotation product in LDS, every round = NP leader lanes
 // computing rotations + every thread rebuilding its elements of J^T A J and W J into the other
@@ -857,10 +903,33 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   // orthonormalise the columns of Yin into Qout ("SVQB" on the column-normalised block, so that
   // the widely different column norms a Chebyshev filter leaves behind do not enter the
   // conditioning of the Gram matrix); returns the condition estimate of the scaled Gram matrix
+  const bool tiny_ok = b % 16 == 0 && tuning("eig_small_gemm", 1);
   auto small_gemm = [&](const double *Am, const double *Bm, double alpha, double beta, const double *E,
-                        double *out) {  // out = alpha Am Bm + beta E   (b x b, column-major)
+                        double *out) -> int {  // out = alpha Am Bm + beta E   (b x b, column-major)
+    if (tiny_ok) {
+      SmallGemmPair pr;
+      pr.g[0] = SmallGemm{Am, Bm, E, out, alpha, beta};
+      pr.g[1] = pr.g[0];
+      ProfScope ps("small_gemm_kernel", st, 2.0 * (double)b * b * b);
+      hipLaunchKernelGGL(small_gemm_kernel, dim3(b / 16, b / 16, 1), dim3(64), 0, st, pr, b);
+      return check_launch("small_gemm_kernel");
+    }
     return gemm_launch(st, b, b, b, alpha, Am, 1, b, Bm, 1, b, beta, E, 1, b, out, 1, b, w.gemm_ws, w.gemm_ws_elems,
                        0.0, nullptr);
+  };
+  // two independent products in one launch: out0 = A0 B0, out1 = A1 B1
+  auto small_gemm2 = [&](const double *A0, const double *B0, double *out0, const double *A1, const double *B1,
+                         double *out1) -> int {
+    if (tiny_ok) {
+      SmallGemmPair pr;
+      pr.g[0] = SmallGemm{A0, B0, nullptr, out0, 1.0, 0.0};
+      pr.g[1] = SmallGemm{A1, B1, nullptr, out1, 1.0, 0.0};
+      ProfScope ps("small_gemm_kernel", st, 4.0 * (double)b * b * b);
+      hipLaunchKernelGGL(small_gemm_kernel, dim3(b / 16, b / 16, 2), dim3(64), 0, st, pr, b);
+      return check_launch("small_gemm_kernel");
+    }
+    FLGP_TRY(small_gemm(A0, B0, 1.0, 0.0, nullptr, out0));
+    return small_gemm(A1, B1, 1.0, 0.0, nullptr, out1);
   };
   auto dist_to_identity = [&](const double *M, double *out) -> int {
     hipLaunchKernelGGL(dist_to_identity_kernel, dim3(1), dim3(1024), 0, st, M, b, w.res);
@@ -893,8 +962,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
       bool ok = false;
       for (int k = 0; k < kmax; ++k) {
         FLGP_TRY(small_gemm(Zc, Yc, -0.5, 1.5, w.Id, Mm));
-        FLGP_TRY(small_gemm(Yc, Mm, 1.0, 0.0, nullptr, Yn));
-        FLGP_TRY(small_gemm(Mm, Zc, 1.0, 0.0, nullptr, Zn));
+        FLGP_TRY(small_gemm2(Yc, Mm, Yn, Mm, Zc, Zn));
         std::swap(Yc, Yn);
         std::swap(Zc, Zn);
       }
@@ -940,8 +1008,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
         bool ok = false;
         for (int k = 0; k < 72 && !ok; ++k) {
           FLGP_TRY(small_gemm(Zc, Yc, -0.5, 1.5, w.Id, Mm));
-          FLGP_TRY(small_gemm(Yc, Mm, 1.0, 0.0, nullptr, Yn));
-          FLGP_TRY(small_gemm(Mm, Zc, 1.0, 0.0, nullptr, Zn));
+          FLGP_TRY(small_gemm2(Yc, Mm, Yn, Mm, Zc, Zn));
           std::swap(Yc, Yn);
           std::swap(Zc, Zn);
           if (k >= 8 && k % 3 == 2) {
@@ -1050,9 +1117,13 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     rmax = 0.0;
     for (int j = 0; j < K; ++j) rmax = std::max(rmax, res[j]);
     top = std::max(theta[0], 1e-300);
-    if (tuning("eig_verbose", 0))
-      fprintf(stderr, "[flgp eig] it=%d gprods=%d theta0=%.15g thetaK=%.6g cut=%.6g rmax=%.3e cond=%.2e sweeps=%d\n",
-              it, gprods, theta[0], theta[K - 1], theta[b - 1], rmax, cond, sweeps);
+    if (tuning("eig_verbose", 0)) {
+      int npre = 0, nconv = 0;
+      while (npre < K && res[npre] <= tol * top) ++npre;
+      for (int j = 0; j < K; ++j) nconv += res[j] <= tol * top;
+      fprintf(stderr, "[flgp eig] it=%d gprods=%d theta0=%.15g thetaK=%.6g cut=%.6g rmax=%.3e cond=%.2e sweeps=%d conv=%d prefix=%d\n",
+              it, gprods, theta[0], theta[K - 1], theta[b - 1], rmax, cond, sweeps, nconv, npre);
+    }
     if (rmax <= tol * top) { converged = true; result = A; break; }
     if (it >= 3 && rmax_meas > 0.0 && rmax / top < rmax_meas) {
       const double rt = std::pow((rmax / top) / rmax_meas, 1.0 / (double)(it - it_meas));
