@@ -23,10 +23,14 @@
 namespace flgp {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
+typedef double d2 __attribute__((ext_vector_type(2)));
 
 constexpr int GB = 128;        // block tile (rows and cols)
 constexpr int GK = 16;         // k depth per stage
-constexpr int GLD = GB + 16;   // padded LDS row stride (doubles)
+#ifndef GEMM_GLD_PAD
+#define GEMM_GLD_PAD 17
+#endif
+constexpr int GLD = GB + GEMM_GLD_PAD;   // padded LDS row stride (doubles)
 
 struct GemmArgs {
   int M, N, Kd;
@@ -36,34 +40,52 @@ struct GemmArgs {
   const double *E; long e_is, e_js;    // + beta * E(i,j)
   const double *E2;                    // + gamma * E2(i,j), same strides as E
   double *C; long c_is, c_js;
+  int shift_edges;                    // edge tiles slide back inside the matrix (they recompute a few columns / rows)
   int ksplit_len;                     // k range per blockIdx.z (multiple of GK); partials when gridDim.z > 1
   double *part;                       // [z][M][N] row-major partials
 };
 
-// load a 128(rows) x 16(k) operand tile into registers: 8 elements per thread.
-// ROWC: element (row, k) at base[row*rs + k*ks]; mapping 0 (row-contiguous) or 1 (k-contiguous / generic)
-__device__ __forceinline__ void tile_load(double (&reg)[8], const double *__restrict__ base, long rs, long ks,
-                                          int row0, int nrows, int k0, int kend, bool row_contig, int tid) {
+// ---- operand staging: a 128(rows) x 16(k) tile goes global -> 8 registers per thread -> LDS [k][row].
+// Three thread mappings, chosen per operand and per stage (uniform over the workgroup):
+//   RC  row-contiguous operand, tile and stage fully inside: each thread loads two adjacent rows at once
+//       (one 16-byte load; k = tid>>6 + 4 rep) -- four loads and four LDS stores per stage;
+//   KC  k-contiguous operand, fully inside: two adjacent k of one row per load (row = tid>>3 + 32 rep);
+//   GEN anything else (edge tiles, the k tail, arbitrary strides): one element per load, out-of-range
+//       elements read a clamped address and are zeroed by a select.
+// Measured on the 5120 x 256 x 5120 product: the predicated one-element path costs 14 % of the run time,
+// which is why the interior of the problem does not take it.
+enum { LOAD_GEN = 0, LOAD_RC = 1, LOAD_KC = 2 };
+
+__device__ __forceinline__ void tile_load_gen(double (&reg)[8], const double *__restrict__ base, long rs, long ks,
+                                              int row0, int nrows, int k0, int kend, bool row_contig, int tid) {
   if (row_contig) {
     const int row = row0 + (tid & 127);
     const int kb = tid >> 7;
+    const bool rv = row < nrows;
+    const double *pr = base + (size_t)(rv ? row : nrows - 1) * rs;
 #pragma unroll
     for (int rep = 0; rep < 8; ++rep) {
       const int k = k0 + kb + 2 * rep;
-      reg[rep] = (row < nrows && k < kend) ? base[(size_t)row * rs + (size_t)k * ks] : 0.0;
+      const bool kv = k < kend;
+      const double v = pr[(size_t)(kv ? k : kend - 1) * ks];
+      reg[rep] = (rv && kv) ? v : 0.0;
     }
   } else {
     const int k = k0 + (tid & 15);
     const int rb = tid >> 4;
+    const bool kv = k < kend;
+    const double *pk = base + (size_t)(kv ? k : kend - 1) * ks;
 #pragma unroll
     for (int rep = 0; rep < 8; ++rep) {
       const int row = row0 + rb + 16 * rep;
-      reg[rep] = (row < nrows && k < kend) ? base[(size_t)row * rs + (size_t)k * ks] : 0.0;
+      const bool rv = row < nrows;
+      const double v = pk[(size_t)(rv ? row : nrows - 1) * rs];
+      reg[rep] = (rv && kv) ? v : 0.0;
     }
   }
 }
 
-__device__ __forceinline__ void tile_store(const double (&reg)[8], double *__restrict__ lds, bool row_contig, int tid) {
+__device__ __forceinline__ void tile_store_gen(const double (&reg)[8], double *__restrict__ lds, bool row_contig, int tid) {
   if (row_contig) {
     const int row = tid & 127, kb = tid >> 7;
 #pragma unroll
@@ -75,9 +97,85 @@ __device__ __forceinline__ void tile_store(const double (&reg)[8], double *__res
   }
 }
 
+struct Operand {
+  const double *base;   // element (row, k) at base[row * rs + k * ks]
+  long rs, ks;
+  int row0, nrows;
+  int mode;             // LOAD_RC / LOAD_KC when the whole tile is inside and the layout allows, else LOAD_GEN
+  bool row_contig;
+  const double *fast;   // per-thread pointer of the fast mappings at k = 0
+};
+
+__device__ __forceinline__ Operand make_operand(const double *base, long rs, long ks, int row0, int nrows, int tid) {
+  Operand o;
+  o.base = base; o.rs = rs; o.ks = ks; o.row0 = row0; o.nrows = nrows;
+  o.row_contig = (rs == 1);
+  o.mode = LOAD_GEN;
+  o.fast = base;
+  const bool inside = row0 + GB <= nrows;
+  const bool al16 = (((size_t)base) & 15) == 0;
+  if (inside && al16 && rs == 1 && (ks & 1) == 0) {
+    o.mode = LOAD_RC;
+    o.fast = base + (size_t)(row0 + 2 * (tid & 63)) + (size_t)(tid >> 6) * ks;
+  } else if (inside && al16 && ks == 1 && (rs & 1) == 0) {
+    o.mode = LOAD_KC;
+    o.fast = base + (size_t)(row0 + (tid >> 3)) * rs + (size_t)(2 * (tid & 7));
+  }
+  return o;
+}
+
+// stage [k0, k0 + GK) of the operand into registers; `full` = the stage lies inside [., kend)
+__device__ __forceinline__ void stage_load(double (&reg)[8], const Operand &o, int k0, int kend, bool full, int tid) {
+  if (full && o.mode == LOAD_RC) {
+    const double *p = o.fast + (size_t)k0 * o.ks;
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep) {
+      const d2 v = *(const d2 *)(p + (size_t)(4 * rep) * o.ks);
+      reg[2 * rep] = v[0];
+      reg[2 * rep + 1] = v[1];
+    }
+  } else if (full && o.mode == LOAD_KC) {
+    const double *p = o.fast + k0;
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep) {
+      const d2 v = *(const d2 *)(p + (size_t)(32 * rep) * o.rs);
+      reg[2 * rep] = v[0];
+      reg[2 * rep + 1] = v[1];
+    }
+  } else {
+    tile_load_gen(reg, o.base, o.rs, o.ks, o.row0, o.nrows, k0, kend, o.row_contig, tid);
+  }
+}
+
+__device__ __forceinline__ void stage_store(const double (&reg)[8], double *__restrict__ lds, const Operand &o, bool full,
+                                            int tid) {
+  if (full && o.mode == LOAD_RC) {
+    double *q = lds + (tid >> 6) * GLD + 2 * (tid & 63);
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep) {
+      q[(4 * rep) * GLD] = reg[2 * rep];
+      q[(4 * rep) * GLD + 1] = reg[2 * rep + 1];
+    }
+  } else if (full && o.mode == LOAD_KC) {
+    double *q = lds + (2 * (tid & 7)) * GLD + (tid >> 3);
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep) {
+      q[32 * rep] = reg[2 * rep];
+      q[GLD + 32 * rep] = reg[2 * rep + 1];
+    }
+  } else {
+    tile_store_gen(reg, lds, o.row_contig, tid);
+  }
+}
+
+// The inner product runs on v_mfma_f64_16x16x4_f64.  (The 4x4x4 four-block form was tried as well: both
+// forms sustain 72-76 TFLOP/s in the bare inner loop -- scripts/ubench_inner.hip -- so the form with the
+// fewer operand reads stays.  Layout of the 4x4x4 form, probed on the device with scripts/probe_mfma4.hip:
+// A_b(i,k) in lane i + 4b + 16k, B_b(k,j) in lane j + 4b + 16k, D_b(i,j) in lane j + 4b + 16i.)
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
-  __shared__ double As[GK * GLD];
-  __shared__ double Bs[GK * GLD];
+  // two LDS stages: the tile of stage s+1 is written while stage s is being multiplied, one barrier per stage
+  __shared__ double As2[2][GK * GLD];
+  __shared__ double Bs2[2][GK * GLD];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
@@ -94,13 +192,22 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   // share the long operand's panel through L2 and the short operand stays L2 resident
   const int tm = (ntm <= ntn) ? bid % ntm : bid / ntn;
   const int tn = (ntm <= ntn) ? bid / ntm : bid % ntn;
-  const int row0 = tm * GB, col0 = tn * GB;
+  int row0 = tm * GB, col0 = tn * GB;
+  // An edge tile would stage its operands through the predicated path for all of its k range and, being
+  // the slowest block, set the run time (measured: 286 us at 4992, 351 us at 5000).  Where it is safe the
+  // tile is moved back inside instead and recomputes rows / columns its neighbour also writes -- the same
+  // values, from the same operations in the same order.
+  if (g.shift_edges) {
+    if (row0 + GB > g.M && g.M >= GB) row0 = g.M - GB;
+    if (col0 + GB > g.N && g.N >= GB) col0 = g.N - GB;
+  }
 
   const int kbeg = blockIdx.z * g.ksplit_len;
   int kend = kbeg + g.ksplit_len;
   if (kend > g.Kd) kend = g.Kd;
 
-  const bool a_rc = (g.a_is == 1), b_rc = (g.b_js == 1);
+  const Operand oa = make_operand(g.A, g.a_is, g.a_ks, row0, g.M, tid);
+  const Operand ob = make_operand(g.B, g.b_js, g.b_ks, col0, g.N, tid);
   d4 acc[4][4];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
@@ -108,18 +215,33 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
 
   double ra[8], rb[8];
-  tile_load(ra, g.A, g.a_is, g.a_ks, row0, g.M, kbeg, kend, a_rc, tid);
-  tile_load(rb, g.B, g.b_js, g.b_ks, col0, g.N, kbeg, kend, b_rc, tid);
+  {
+    const bool f0 = kbeg + GK <= kend;
+    stage_load(ra, oa, kbeg, kend, f0, tid);
+    stage_load(rb, ob, kbeg, kend, f0, tid);
+    stage_store(ra, As2[0], oa, f0, tid);
+    stage_store(rb, Bs2[0], ob, f0, tid);
+    if (kbeg + GK < kend) {
+      const bool f1 = kbeg + 2 * GK <= kend;
+      stage_load(ra, oa, kbeg + GK, kend, f1, tid);
+      stage_load(rb, ob, kbeg + GK, kend, f1, tid);
+    }
+  }
+  __syncthreads();
 
   const int fr = lane & 15, fk = lane >> 4;
-  for (int k0 = kbeg; k0 < kend; k0 += GK) {
-    __syncthreads();  // previous stage's fragment reads are done
-    tile_store(ra, As, a_rc, tid);
-    tile_store(rb, Bs, b_rc, tid);
-    __syncthreads();
-    if (k0 + GK < kend) {  // prefetch the next stage while this one computes
-      tile_load(ra, g.A, g.a_is, g.a_ks, row0, g.M, k0 + GK, kend, a_rc, tid);
-      tile_load(rb, g.B, g.b_js, g.b_ks, col0, g.N, k0 + GK, kend, b_rc, tid);
+  int cur = 0;
+  for (int k0 = kbeg; k0 < kend; k0 += GK, cur ^= 1) {
+    const double *As = As2[cur], *Bs = Bs2[cur];
+    if (k0 + GK < kend) {      // stage s+1 goes into the other buffer (last read before the previous barrier)
+      const bool f1 = k0 + 2 * GK <= kend;
+      stage_store(ra, As2[cur ^ 1], oa, f1, tid);
+      stage_store(rb, Bs2[cur ^ 1], ob, f1, tid);
+      if (k0 + 2 * GK < kend) {  // and stage s+2 starts its way from HBM / L2
+        const bool f2 = k0 + 3 * GK <= kend;
+        stage_load(ra, oa, k0 + 2 * GK, kend, f2, tid);
+        stage_load(rb, ob, k0 + 2 * GK, kend, f2, tid);
+      }
     }
 #pragma unroll
     for (int kk = 0; kk < GK; kk += 4) {
@@ -134,6 +256,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         for (int ni = 0; ni < 4; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
     }
+    __syncthreads();
   }
 
   // epilogue: D(row = (lane>>4) + 4*reg, col = lane&15) of each 16x16 tile
@@ -212,6 +335,8 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
   nsplit = ceil_div(Kd > 0 ? Kd : 1, klen);
   g.ksplit_len = klen;
   g.part = work;
+  // overlapping tiles write some elements twice: harmless unless the epilogue reads what it overwrites
+  g.shift_edges = (nsplit > 1 || ((const double *)g.C != g.E && (const double *)g.C != g.E2)) ? 1 : 0;
   {
     ProfScope ps("gemm_f64_kernel", st, 2.0 * (double)M * (double)N * (double)Kd);
     // second record per shape class (large / medium / small) for the bench breakdown

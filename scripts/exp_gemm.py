@@ -10,6 +10,9 @@ sys.path.insert(0, ROOT)
 from flgp_amd import _lib  # noqa: E402
 
 L = _lib.lib()
+for kv in sys.argv[1:]:
+    k, v = kv.split("=")
+    L.flgp_set_tuning(k.encode(), int(v))
 st = torch.cuda.current_stream().cuda_stream
 
 
