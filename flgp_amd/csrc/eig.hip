@@ -1099,9 +1099,9 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     //  never converge, so their diagonal block of T stays dense -- measured: 2 sweeps put rmax
     //  back to 4e-2.  jacobi_refine diagonalises that block first.)
     if (it < 2)         // bounds and a rough Ritz basis are all that is needed yet: loose threshold, capped sweeps
-      FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps, tuning(it == 0 ? "eig_sweeps_it0" : "eig_sweeps_it1", it == 0 ? 5 : -1), 1e10));
+      FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps, tuning(it == 0 ? "eig_sweeps_it0" : "eig_sweeps_it1", 3), 1e10));
     else if (rmax_prev > 5e-2)
-      FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps, -1, 1e6));
+      FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps, tuning("eig_sweeps_it2", 3), 1e6));
     else
       FLGP_TRY(jacobi_refine(st, w.T, b, K, w, lam, &sweeps, rmax_prev > 3e-3 ? 3 : (rmax_prev > 1e-6 ? 2 : 1)));
     FLGP_TRY(sorted_basis(st, lam, nullptr, b, b, w, order));
