@@ -251,6 +251,9 @@ __global__ void transpose_v_kernel(const double *__restrict__ V, int ldv, int s,
 // s*K*8 bytes); the 64 x 64 tile is turned through LDS so that the column-major output is written
 // in 512-byte pieces as well.  Arithmetic as u_recover_kernel: acc = 0; acc += A(i,a) V(idx,k)
 // (a ascending, mul then add); (acc / sigma_k) * scale.
+#ifndef U_RECOVER_UNROLL
+#define U_RECOVER_UNROLL 8
+#endif
 __global__ __launch_bounds__(256) void u_recover_tiled_kernel(const int *__restrict__ ell_idx,
                                                               const double *__restrict__ val, int n, int r,
                                                               const double *__restrict__ Vt,
@@ -264,15 +267,27 @@ __global__ __launch_bounds__(256) void u_recover_tiled_kernel(const int *__restr
   const bool kok = k < K;
   double sigma = 1.0;
   if (kok) { const double ev = eig[k]; sigma = __builtin_sqrt(ev > 0.0 ? ev : 0.0); }
-  for (int il = wave * 16; il < wave * 16 + 16; ++il) {
-    const long i = i0 + il;
-    double acc = 0.0;
-    if (i < n && kok) {
-      const int *id = ell_idx + (size_t)i * r;      // wave-uniform addresses: scalar loads
-      const double *va = val + (size_t)i * r;
-      for (int a = 0; a < r; ++a) acc += va[a] * Vt[(size_t)id[a] * K + k];
+  // UR rows in flight per wave: their UR r gathers are issued before the first one is consumed
+  constexpr int UR = U_RECOVER_UNROLL;
+  const double inv_guard = kok ? 1.0 : 0.0;
+  const int kk = kok ? k : 0;
+  for (int il = wave * 16; il < wave * 16 + 16; il += UR) {
+    double acc[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u) acc[u] = 0.0;
+    for (int a = 0; a < r; ++a) {
+      double v[UR], z[UR];
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        const long i = (i0 + il + u < n) ? i0 + il + u : n - 1;   // wave-uniform: scalar loads
+        z[u] = val[(size_t)i * r + a];
+        v[u] = Vt[(size_t)ell_idx[(size_t)i * r + a] * K + kk];
+      }
+#pragma unroll
+      for (int u = 0; u < UR; ++u) acc[u] += z[u] * v[u];
     }
-    tile[lane][il] = (acc / sigma) * scale;
+#pragma unroll
+    for (int u = 0; u < UR; ++u) tile[lane][il + u] = ((acc[u] * inv_guard) / sigma) * scale;
   }
   __syncthreads();
   const int i = tid & 63;
