@@ -792,7 +792,7 @@ static int jacobi_refine(hipStream_t st, const double *T, int b, int K, EigWork 
                                  (int)lds_small));
     const double tol_g = 4.0 * std::sqrt((double)g) * 1.1102230246251565e-16;
     hipLaunchKernelGGL(small_sym_eig_kernel<64>, dim3(1), dim3(1024), lds_small, st, T + (size_t)K * b + K, b, g, Vg,
-                       tol_g, tuning("eig_guard_sweeps", 3));
+                       tol_g, tuning("eig_guard_sweeps", 2));
     FLGP_TRY(check_launch("small_sym_eig_kernel"));
   } else {
     // a guard block too large for one workgroup's LDS: the block Jacobi on the g x g matrix itself
@@ -1103,7 +1103,8 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     else if (rmax_prev > 5e-2)
       FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps, tuning("eig_sweeps_it2", 3), 1e6));
     else
-      FLGP_TRY(jacobi_refine(st, w.T, b, K, w, lam, &sweeps, rmax_prev > 3e-3 ? 3 : (rmax_prev > 1e-6 ? 2 : 1)));
+      FLGP_TRY(jacobi_refine(st, w.T, b, K, w, lam, &sweeps,
+                             std::max(1, (rmax_prev > 3e-3 ? 3 : (rmax_prev > 1e-6 ? 2 : 1)) - tuning("eig_refine_minus", 0))));
     FLGP_TRY(sorted_basis(st, lam, nullptr, b, b, w, order));
     for (int j = 0; j < b; ++j) theta[j] = lam[order[j]];
     FLGP_TRY(rotate(Q, w.W, A));   // A = Ritz vectors
