@@ -806,9 +806,17 @@ static int jacobi_refine(hipStream_t st, const double *T, int b, int K, EigWork 
   }
   hipLaunchKernelGGL(embed_block_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, Vg, g, K, b, w.JV);
   FLGP_TRY(check_launch("embed_block_kernel"));
-  // JB = T JV
-  FLGP_TRY(gemm_launch(st, b, b, b, 1.0, T, 1, b, w.JV, 1, b, 0.0, nullptr, 0, 0, w.JB, 1, b, w.gemm_ws, w.gemm_ws_elems,
-                       0.0, nullptr));
+  // JB = T JV  (wave-per-tile kernel: no workspace, so this may run beside the big GEMMs of another stream)
+  if (b % 16 == 0) {
+    SmallGemmPair pr;
+    pr.g[0] = SmallGemm{T, w.JV, nullptr, w.JB, 1.0, 0.0};
+    pr.g[1] = pr.g[0];
+    hipLaunchKernelGGL(small_gemm_kernel, dim3(b / 16, b / 16, 1), dim3(64), 0, st, pr, b);
+    FLGP_TRY(check_launch("small_gemm_kernel"));
+  } else {
+    FLGP_TRY(gemm_launch(st, b, b, b, 1.0, T, 1, b, w.JV, 1, b, 0.0, nullptr, 0, 0, w.JB, 1, b, w.gemm_ws, w.gemm_ws_elems,
+                         0.0, nullptr));
+  }
   return jacobi_run(st, b, w, h_lam, sweeps_out, sweeps, 1.0, false);
 }
 
@@ -1074,9 +1082,96 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   const int rr_every = tuning("eig_rr_every", 3);
   int since_rr = 0, it_meas = 0;
   double rate = 0.1, rmax_meas = 0.0;
+
+  // second stream: late Rayleigh-Ritz refinements (eight workgroups of Jacobi) run beside the filter's GEMMs
+  struct Side {
+    hipStream_t st = nullptr;
+    hipEvent_t ev = nullptr;
+    ~Side() {
+      if (ev) (void)hipEventDestroy(ev);
+      if (st) (void)hipStreamDestroy(st);
+    }
+  } side;
+  if (tuning("eig_overlap", 1)) {
+    if (hipStreamCreateWithFlags(&side.st, hipStreamNonBlocking) != hipSuccess) side.st = nullptr;
+    if (side.st && hipEventCreateWithFlags(&side.ev, hipEventDisableTiming) != hipSuccess) side.ev = nullptr;
+  }
+  const bool can_overlap = side.st && side.ev;
+
+  // ---- Chebyshev filter on [0, cut], scaled to 1 at the top Ritz value
+  struct FilterPlan { double c, e, sigma1; int m; };
+  auto plan_filter = [&](double top, int it_) {
+    const int cut_pos = K + (b - K) * tuning("eig_cut_pct", 100) / 100;
+    double cut = theta[std::min(b - 1, std::max(K, cut_pos - 1))];
+    if (!(cut > 0.0)) cut = 1e-3 * top;
+    if (cut > 0.999 * top) cut = 0.999 * top;   // degenerate block: keep a valid interval
+    FilterPlan fp;
+    fp.e = 0.5 * cut; fp.c = 0.5 * cut;
+    const double g1 = (top - fp.c) / fp.e;      // >= 1
+    // degree: amplification T_m(g1) of the top direction capped per outer iteration
+    // (gentler while the block is still far from the invariant subspace)
+    const double amp = std::pow(10.0, (double)((it_ < 2) ? tuning("eig_amp_exp_early", 3) : tuning("eig_amp_exp", 7)));
+    int m = (int)std::floor(std::acosh(amp) / std::acosh(std::max(g1, 1.0 + 1e-12)));
+    fp.m = std::max(2, std::min(m, 40));
+    fp.sigma1 = fp.e / (top - fp.c);
+    return fp;
+  };
+  // p(G) A given B = G A; A, f1, f2 are overwritten (B is not); returns the buffer with the result and
+  // one buffer that is free afterwards
+  auto apply_filter = [&](const FilterPlan &fp, double *A, const double *B, double *f1, double *f2, double **cur_out,
+                          double **spare_out) -> int {
+    double sigma = fp.sigma1;
+    // degree 1: Y = (sigma1/e) (G A - c A) = (sigma1/e) (B - c A), into a free buffer
+    double *prev = A, *cur = f1, *next = f2;
+    hipLaunchKernelGGL(eig_axpby_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, st, fp.sigma1 / fp.e, B,
+                       -fp.sigma1 * fp.c / fp.e, A, cur, tot);
+    FLGP_TRY(check_launch("eig_axpby_kernel"));
+    for (int deg = 2; deg <= fp.m; ++deg) {
+      const double sn = 1.0 / (2.0 / fp.sigma1 - sigma);
+      // next = (2 sn / e) (G cur - c cur) - sigma sn prev
+      FLGP_TRY(gemmG(cur, 2.0 * sn / fp.e, -2.0 * sn * fp.c / fp.e, cur, -sigma * sn, prev, next));
+      ++gprods;
+      double *t3 = prev; prev = cur; cur = next; next = t3;
+      sigma = sn;
+    }
+    *cur_out = cur;
+    *spare_out = prev;
+    return FLGP_OK;
+  };
+  // residuals of the K wanted pairs (A = Ritz vectors, B = G A); synchronises `st`
+  auto residuals = [&](const double *A, const double *B, double *rmax_out) -> int {
+    FLGP_HIP(hipMemcpyAsync(w.lam, theta.data(), sizeof(double) * b, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(resid_kernel, dim3(K), dim3(256), 0, st, B, A, s, s, w.lam, w.res);
+    FLGP_TRY(check_launch("resid_kernel"));
+    FLGP_HIP(hipMemcpyAsync(res.data(), w.res, sizeof(double) * K, hipMemcpyDeviceToHost, st));
+    FLGP_HIP(hipStreamSynchronize(st));
+    double rmax = 0.0;
+    for (int j = 0; j < K; ++j) rmax = std::max(rmax, res[j]);
+    *rmax_out = rmax;
+    return FLGP_OK;
+  };
+  auto after_rr = [&](double rmax, double top, bool overlapped) {   // book-keeping shared by both orders
+    if (tuning("eig_verbose", 0)) {
+      int npre = 0, nconv = 0;
+      while (npre < K && res[npre] <= tol * top) ++npre;
+      for (int j = 0; j < K; ++j) nconv += res[j] <= tol * top;
+      fprintf(stderr, "[flgp eig] it=%d gprods=%d theta0=%.15g thetaK=%.6g cut=%.6g rmax=%.3e cond=%.2e sweeps=%d conv=%d prefix=%d%s\n",
+              it, gprods, theta[0], theta[K - 1], theta[b - 1], rmax, cond, sweeps, nconv, npre, overlapped ? " (overlapped)" : "");
+    }
+    if (rmax <= tol * top) return true;
+    if (it >= 3 && rmax_meas > 0.0 && rmax / top < rmax_meas) {
+      const double rt = std::pow((rmax / top) / rmax_meas, 1.0 / (double)(it - it_meas));
+      rate = std::min(0.5, std::max(0.02, rt));
+    }
+    rmax_meas = rmax / top; it_meas = it;
+    rmax_prev = rmax / top;
+    return false;
+  };
+
   for (it = 0; it < max_it; ++it) {
     double *Z = F[0];
     double *A, *B, *free1, *free2;     // Ritz vectors, G * Ritz vectors, two free s x b buffers
+    double *cur = nullptr, *spare = nullptr;   // filtered block; a buffer that is free after the filter
     FLGP_TRY(gemmG(Q, 1.0, 0.0, nullptr, 0.0, nullptr, Z));
     ++gprods;
     // Rayleigh-Ritz may be skipped on some late iterations (rr_every > 1): the block is then used as it
@@ -1087,85 +1182,77 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     const bool near_done = rmax_prev * rate <= 4.0 * tol;
     const bool early_skip = tuning("eig_skip_it1", 0) && it == 1;
     const bool do_rr = !early_skip && !(rr_every > 1 && it >= 3 && rmax_prev < 1e-3 && since_rr + 1 < rr_every && !near_done);
+    // Late Rayleigh-Ritz steps only refine a nearly diagonal T: the filter does not wait for them.  It is
+    // linear, p(G) (Q W) = (p(G) Q) W, so it runs on the block as it is, with the bounds of the previous
+    // step (once the residuals are below 1e-3 they move in the third digit: measured, earlier steps lose
+    // more to the stale interval than they gain), while the refinement runs on the second stream; the
+    // rotation W is applied to the filtered block afterwards.  Not on the step that is expected to
+    // converge: there the filter's products would be thrown away.
+    const bool overlap = can_overlap && do_rr && it >= 3 && !near_done &&
+                         rmax_prev <= 1e-6 * (double)tuning("eig_overlap_below_e6", 1000);
     double rmax = rmax_prev * rate, top = std::max(theta[0], 1e-300);
-    if (do_rr) {
-    since_rr = 0;
-    A = F[1]; B = F[2]; free1 = Q; free2 = Z;
-    // ---- Rayleigh-Ritz on span(Q): Z = G Q, T = Q^T Z, T = W Th W^T
-    FLGP_TRY(gram_small(Q, Z, w.T));
-    // T is far from diagonal only while the block is far from invariant: full Jacobi for the first
-    // iterations, afterwards a single sweep refines the (already nearly diagonal) Ritz basis
-    // (a fixed small number of global sweeps alone is NOT enough, even late: the guard columns
-    //  never converge, so their diagonal block of T stays dense -- measured: 2 sweeps put rmax
-    //  back to 4e-2.  jacobi_refine diagonalises that block first.)
-    if (it < 2)         // bounds and a rough Ritz basis are all that is needed yet: loose threshold, capped sweeps
-      FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps, tuning(it == 0 ? "eig_sweeps_it0" : "eig_sweeps_it1", 3), 1e10));
-    else if (rmax_prev > 5e-2)
-      FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps, tuning("eig_sweeps_it2", 3), 1e6));
-    else
-      FLGP_TRY(jacobi_refine(st, w.T, b, K, w, lam, &sweeps,
+    if (do_rr && overlap) {
+      since_rr = 0;
+      FLGP_TRY(gram_small(Q, Z, w.T));
+      FLGP_HIP(hipEventRecord(side.ev, st));
+      FLGP_HIP(hipMemcpyAsync(w.Qold, Q, sizeof(double) * (size_t)tot, hipMemcpyDeviceToDevice, st));
+      const FilterPlan fp = plan_filter(top, it);
+      FLGP_TRY(apply_filter(fp, Q, Z, F[1], F[2], &cur, &spare));
+      // the other stream: T = W Th W^T
+      FLGP_HIP(hipStreamWaitEvent(side.st, side.ev, 0));
+      FLGP_TRY(jacobi_refine(side.st, w.T, b, K, w, lam, &sweeps,
                              std::max(1, (rmax_prev > 3e-3 ? 3 : (rmax_prev > 1e-6 ? 2 : 1)) - tuning("eig_refine_minus", 0))));
-    FLGP_TRY(sorted_basis(st, lam, nullptr, b, b, w, order));
-    for (int j = 0; j < b; ++j) theta[j] = lam[order[j]];
-    FLGP_TRY(rotate(Q, w.W, A));   // A = Ritz vectors
-    FLGP_TRY(rotate(Z, w.W, B));   // B = G * Ritz vectors
-    // ---- residuals of the K wanted pairs
-    FLGP_HIP(hipMemcpyAsync(w.lam, theta.data(), sizeof(double) * b, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(resid_kernel, dim3(K), dim3(256), 0, st, B, A, s, s, w.lam, w.res);
-    FLGP_TRY(check_launch("resid_kernel"));
-    FLGP_HIP(hipMemcpyAsync(res.data(), w.res, sizeof(double) * K, hipMemcpyDeviceToHost, st));
-    FLGP_HIP(hipStreamSynchronize(st));
-    rmax = 0.0;
-    for (int j = 0; j < K; ++j) rmax = std::max(rmax, res[j]);
-    top = std::max(theta[0], 1e-300);
-    if (tuning("eig_verbose", 0)) {
-      int npre = 0, nconv = 0;
-      while (npre < K && res[npre] <= tol * top) ++npre;
-      for (int j = 0; j < K; ++j) nconv += res[j] <= tol * top;
-      fprintf(stderr, "[flgp eig] it=%d gprods=%d theta0=%.15g thetaK=%.6g cut=%.6g rmax=%.3e cond=%.2e sweeps=%d conv=%d prefix=%d\n",
-              it, gprods, theta[0], theta[K - 1], theta[b - 1], rmax, cond, sweeps, nconv, npre);
-    }
-    if (rmax <= tol * top) { converged = true; result = A; break; }
-    if (it >= 3 && rmax_meas > 0.0 && rmax / top < rmax_meas) {
-      const double rt = std::pow((rmax / top) / rmax_meas, 1.0 / (double)(it - it_meas));
-      rate = std::min(0.5, std::max(0.02, rt));
-    }
-    rmax_meas = rmax / top; it_meas = it;
-    rmax_prev = rmax / top;
+      FLGP_TRY(sorted_basis(side.st, lam, nullptr, b, b, w, order));   // synchronises the side stream: W is ready
+      for (int j = 0; j < b; ++j) theta[j] = lam[order[j]];
+      // the two buffers of {Q, F1, F2} that do not hold the filtered block take A and B
+      double *trio[3] = {Q, F[1], F[2]};
+      double *x[2]; int nx = 0;
+      for (int q = 0; q < 3; ++q) if (trio[q] != cur) x[nx++] = trio[q];
+      A = x[0]; B = x[1];
+      FLGP_TRY(rotate(w.Qold, w.W, A));   // A = Ritz vectors
+      FLGP_TRY(rotate(Z, w.W, B));        // B = G * Ritz vectors
+      FLGP_TRY(residuals(A, B, &rmax));
+      top = std::max(theta[0], 1e-300);
+      if (after_rr(rmax, top, true)) { converged = true; result = A; break; }
+      FLGP_TRY(rotate(cur, w.W, Z));      // the filtered block in the new Ritz order (Z is free by now)
+      FLGP_HIP(hipMemcpyAsync(w.Qold, A, sizeof(double) * (size_t)tot, hipMemcpyDeviceToDevice, st));
+      free1 = cur; free2 = Z;
+      spare = cur;
+      cur = Z;
     } else {
-      ++since_rr;
-      A = Q; B = Z; free1 = F[1]; free2 = F[2];
-      rmax_prev *= rate;
-    }
-
-    // ---- Chebyshev filter on [0, cut], scaled to 1 at the top Ritz value
-    const int cut_pos = K + (b - K) * tuning("eig_cut_pct", 100) / 100;
-    double cut = theta[std::min(b - 1, std::max(K, cut_pos - 1))];
-    if (!(cut > 0.0)) cut = 1e-3 * top;
-    if (cut > 0.999 * top) cut = 0.999 * top;   // degenerate block: keep a valid interval
-    const double e = 0.5 * cut, c = 0.5 * cut;
-    const double g1 = (top - c) / e;            // >= 1
-    // degree: amplification T_m(g1) of the top direction capped per outer iteration
-    // (gentler while the block is still far from the invariant subspace)
-    const double amp = (it < 2) ? 1e3 : std::pow(10.0, (double)tuning("eig_amp_exp", 7));
-    int m = (int)std::floor(std::acosh(amp) / std::acosh(std::max(g1, 1.0 + 1e-12)));
-    m = std::max(2, std::min(m, 40));
-    const double sigma1 = e / (top - c);
-    double sigma = sigma1;
-    // the Ritz vectors are needed again after the filter (see below): keep a copy
-    FLGP_HIP(hipMemcpyAsync(w.Qold, A, sizeof(double) * (size_t)tot, hipMemcpyDeviceToDevice, st));
-    // degree 1: Y = (sigma1/e) (G A - c A) = (sigma1/e) (B - c A), into a free buffer
-    double *prev = A, *cur = free1, *next = free2;
-    hipLaunchKernelGGL(eig_axpby_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, st, sigma1 / e, B,
-                       -sigma1 * c / e, A, cur, tot);
-    FLGP_TRY(check_launch("eig_axpby_kernel"));
-    for (int deg = 2; deg <= m; ++deg) {
-      const double sn = 1.0 / (2.0 / sigma1 - sigma);
-      // next = (2 sn / e) (G cur - c cur) - sigma sn prev
-      FLGP_TRY(gemmG(cur, 2.0 * sn / e, -2.0 * sn * c / e, cur, -sigma * sn, prev, next));
-      ++gprods;
-      double *t3 = prev; prev = cur; cur = next; next = t3;
-      sigma = sn;
+      if (do_rr) {
+        since_rr = 0;
+        A = F[1]; B = F[2]; free1 = Q; free2 = Z;
+        // ---- Rayleigh-Ritz on span(Q): Z = G Q, T = Q^T Z, T = W Th W^T
+        FLGP_TRY(gram_small(Q, Z, w.T));
+        // T is far from diagonal only while the block is far from invariant: full Jacobi for the first
+        // iterations, afterwards a single sweep refines the (already nearly diagonal) Ritz basis
+        // (a fixed small number of global sweeps alone is NOT enough, even late: the guard columns
+        //  never converge, so their diagonal block of T stays dense -- measured: 2 sweeps put rmax
+        //  back to 4e-2.  jacobi_refine diagonalises that block first.)
+        if (it < 2)         // bounds and a rough Ritz basis are all that is needed yet: loose threshold, capped sweeps
+          FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps, tuning(it == 0 ? "eig_sweeps_it0" : "eig_sweeps_it1", 3), 1e10));
+        else if (rmax_prev > 5e-2)
+          FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps, tuning("eig_sweeps_it2", 3), 1e6));
+        else
+          FLGP_TRY(jacobi_refine(st, w.T, b, K, w, lam, &sweeps,
+                                 std::max(1, (rmax_prev > 3e-3 ? 3 : (rmax_prev > 1e-6 ? 2 : 1)) - tuning("eig_refine_minus", 0))));
+        FLGP_TRY(sorted_basis(st, lam, nullptr, b, b, w, order));
+        for (int j = 0; j < b; ++j) theta[j] = lam[order[j]];
+        FLGP_TRY(rotate(Q, w.W, A));   // A = Ritz vectors
+        FLGP_TRY(rotate(Z, w.W, B));   // B = G * Ritz vectors
+        FLGP_TRY(residuals(A, B, &rmax));
+        top = std::max(theta[0], 1e-300);
+        if (after_rr(rmax, top, false)) { converged = true; result = A; break; }
+      } else {
+        ++since_rr;
+        A = Q; B = Z; free1 = F[1]; free2 = F[2];
+        rmax_prev *= rate;
+      }
+      const FilterPlan fp = plan_filter(top, it);
+      // the Ritz vectors are needed again after the filter (see below): keep a copy
+      FLGP_HIP(hipMemcpyAsync(w.Qold, A, sizeof(double) * (size_t)tot, hipMemcpyDeviceToDevice, st));
+      FLGP_TRY(apply_filter(fp, A, B, free1, free2, &cur, &spare));
     }
     // ---- de-contaminate: a filtered column y_j = p(G) q_j carries its error components along the
     //      higher Ritz directions amplified by p(th_i)/p(th_j) (up to `amp`).  One Gram-Schmidt pass
@@ -1182,8 +1269,8 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     FLGP_TRY(orth(cur, B, &cond));
     double *R = B;
     if (cond > 1e8) {
-      FLGP_TRY(orth(B, prev, &cond));
-      R = prev;
+      FLGP_TRY(orth(B, spare, &cond));
+      R = spare;
     }
     // new roles: Q = R, the other three buffers are free
     double *pool[4] = {A, B, free1, free2};
