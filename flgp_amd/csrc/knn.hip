@@ -200,6 +200,150 @@ __global__ __launch_bounds__(256) void knn_kernel(const double *__restrict__ X, 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// k-NN on the matrix cores.  v_mfma_f64_16x16x4_f64 IS the oracle's arithmetic: the instruction
+// accumulates its four products as a chain of IEEE FMAs in ascending k, starting from the C
+// operand (probed on the device against all 24 orders, 5e6 elements, scripts/probe_mfma_order.hip:
+// only k = 0,1,2,3 matches, and it matches bit for bit).  A run of DP/4 instructions over
+// k = 0..DP-1 from C = 0 therefore returns exactly  fma(x_{d-1}, u_{d-1}, ... fma(x_1, u_1, x_0 u_0))
+// (fma(x_0, u_0, +0) is the rounded product; a zero of the other sign cannot reach a distance), for
+// 16 points x 16 anchors at a time, with the operand reuse of a GEMM instead of one broadcast
+// operand read per FMA.
+//
+// One wave owns 64 points: their coordinates stay in VGPRs as four 16-point A fragments; anchors come
+// through an LDS tile stored [k][anchor] (the B fragment is then a conflict-free read).  The MFMA
+// result layout spreads a point's 16 new dot products over 16 lanes, so they are turned through LDS
+// ([point][anchor], row stride 17): lane l then reads the 16 values of ITS point and runs the same
+// selection as knn_kernel -- D = fma(-2, dot, |x|^2) + |u|^2 against the r-th best in a register,
+// survivors into a private LDS queue (in ascending anchor order, so the strict '<' insertion keeps
+// the lower index on ties), sorted top-r list in registers, wave-wide drain when a queue fills.
+// ------------------------------------------------------------------------------------------
+typedef double kd4 __attribute__((ext_vector_type(4)));
+
+template <int DP, int RCAP>
+__global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(DP <= 32 ? 2 : 1, 2))) void knn_mfma_kernel(const double *__restrict__ X, int n, int ldx, int d,
+                                                       const double *__restrict__ Ut,
+                                                       const double *__restrict__ uu, int s, int r,
+                                                       int *__restrict__ idx_out,
+                                                       double *__restrict__ dist_out, int ldo) {
+  constexpr int NW = 2;          // waves per workgroup (they share the anchor tile)
+  constexpr int TA = 64;         // anchors per LDS tile = 4 groups of 16
+  constexpr int TLD = TA + 1;    // [k][anchor] row stride
+  constexpr int QC = 8;          // queue slots per point; fullness is checked every four candidates
+  constexpr int NQ = DP / 4;     // MFMAs per 16 x 16 block
+  constexpr int DLD = 17;        // [point][anchor] row stride of the turned dot products
+  __shared__ double tile[DP * TLD];
+  __shared__ double dots[NW][64 * DLD];
+  __shared__ double q_d[NW][QC * 64];
+  __shared__ int q_j[NW][QC * 64];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fk = lane >> 4;
+  const long pbase = (long)blockIdx.x * (64 * NW) + wave * 64;
+
+  // ---- the lane's own point (selection side): |x|^2 by the oracle's chain
+  long i_own = pbase + lane;
+  const bool live = i_own < n;
+  if (!live) i_own = n - 1;     // clamp: computes a duplicate, never stored
+  double xx;
+  {
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      const double xk = (k < d) ? X[(size_t)k * ldx + i_own] : 0.0;
+      acc = (k == 0) ? xk * xk : __builtin_fma(xk, xk, acc);   // zero padding adds exactly 0
+    }
+    xx = acc;
+  }
+  TopList<RCAP> top;
+  top.init(r);
+  int cnt = 0;
+
+  // ---- A fragments: point pt*16 + fr, coordinate 4q + fk
+  double xa[4][NQ];
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt) {
+    long i = pbase + pt * 16 + fr;
+    if (i >= n) i = n - 1;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) xa[pt][q] = (4 * q + fk < d) ? X[(size_t)(4 * q + fk) * ldx + i] : 0.0;
+  }
+
+  auto drain = [&]() {
+    const int c = cnt;
+    for (int q = 0; __any(q < c); ++q) {
+      if (q < c) {
+        const double D = q_d[wave][q * 64 + lane];
+        const int j = q_j[wave][q * 64 + lane];
+        if (D < top.thr()) top.insert(D, j);
+      }
+    }
+    cnt = 0;
+  };
+
+  const int s_pad = (s + 127) / 128 * 128;   // rows of the padded panel (flgp_dev_anchor_rows): zeros, |u|^2 = +inf
+  double *mydots = dots[wave];
+  for (int j0 = 0; j0 < s_pad; j0 += TA) {
+    __syncthreads();
+    {
+      const double *src = Ut + (size_t)j0 * DP;
+      for (int e = tid; e < TA * DP; e += 64 * NW) tile[(e % DP) * TLD + e / DP] = src[e];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int g = 0; g < TA / 16; ++g) {
+      double ub[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) ub[q] = tile[(4 * q + fk) * TLD + g * 16 + fr];
+      // the 16 squared norms of this group: wave-uniform scalar loads, issued ahead of their use
+      double uug[16];
+#pragma unroll
+      for (int a = 0; a < 16; ++a) uug[a] = uu[j0 + g * 16 + a];
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) {
+        kd4 acc = kd4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[pt][q], ub[q], acc, 0, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) mydots[(pt * 16 + fk + 4 * reg) * DLD + fr] = acc[reg];
+      }
+      __threadfence_block();   // one wave: its LDS operations complete in order
+#pragma unroll
+      for (int a = 0; a < 16; ++a) {
+        if ((a & 3) == 0 && __any(cnt > QC - 4)) drain();     // the next four candidates fit for sure
+        const double D = __builtin_fma(-2.0, mydots[lane * DLD + a], xx) + uug[a];
+        if (D < top.thr()) {
+          q_d[wave][cnt * 64 + lane] = D;
+          q_j[wave][cnt * 64 + lane] = j0 + g * 16 + a;
+          ++cnt;
+        }
+      }
+      __threadfence_block();   // the reads above are done before the next group overwrites the block
+    }
+  }
+  drain();
+
+  if (live) {
+#pragma unroll
+    for (int k = 0; k < RCAP; ++k) {
+      const int slot = k - (RCAP - r);
+      if (slot >= 0) {
+        idx_out[(size_t)slot * ldo + i_own] = top.bi[k];
+        if (dist_out) dist_out[(size_t)slot * ldo + i_own] = top.bd[k];
+      }
+    }
+  }
+}
+
+template <int DP, int RCAP>
+static int launch_knn_mfma(hipStream_t st, const double *dX, int n, int ldx, int d, const double *dUt,
+                           const double *duu, int s, int r, int *d_idx, double *d_dist, int ldo) {
+  ProfScope ps("knn_kernel", st, 2.0 * (double)n * (double)s * (double)d);
+  hipLaunchKernelGGL((knn_mfma_kernel<DP, RCAP>), dim3(ceil_div(n, 128)), dim3(128), 0, st, dX, n, ldx, d, dUt, duu,
+                     s, r, d_idx, d_dist, ldo);
+  return check_launch("knn_mfma_kernel");
+}
+
 template <int DP, int RCAP, int P, int A, int KS, int QC>
 static int launch_knn(hipStream_t st, const double *dX, int n, int ldx, int d, const double *dUt,
                       const double *duu, int s, int r, int *d_idx, double *d_dist, int ldo) {
@@ -260,6 +404,19 @@ extern "C" int flgp_dev_knn(void *stream, const double *dX, int n, int ldx, int 
   if (n == 0) return FLGP_OK;
   const int rcap = r <= 4 ? 4 : (r <= 8 ? 8 : (r <= 16 ? 16 : 32));
   const int variant = tuning("knn_variant", 0);
+  // The matrix-core kernel wins once the distance itself dominates (measured, n = 4e5, s = 5000, r = 10:
+  // d = 64 11.4 vs 18.8 ms, d = 32 5.4 vs 5.8 ms); at d <= 16 the selection is the larger half of either
+  // kernel and the VALU kernel's three waves per SIMD hide its latencies better (d = 16: 6.7 vs 6.0 ms
+  // per 1e6 points).  knn_mfma = 1 / 0 forces one or the other.
+  const int use_mfma = tuning("knn_mfma", -1);
+  if (use_mfma == 1 || (use_mfma < 0 && dpad >= 32)) {
+#define KNN_MFMA_CASE(DPv, RCv) if (dpad == DPv && rcap == RCv) return launch_knn_mfma<DPv, RCv>(KNN_ARGS);
+    KNN_MFMA_CASE(4, 4) KNN_MFMA_CASE(4, 8) KNN_MFMA_CASE(4, 16) KNN_MFMA_CASE(4, 32)
+    KNN_MFMA_CASE(8, 4) KNN_MFMA_CASE(8, 8) KNN_MFMA_CASE(8, 16) KNN_MFMA_CASE(8, 32)
+    KNN_MFMA_CASE(16, 4) KNN_MFMA_CASE(16, 8) KNN_MFMA_CASE(16, 16) KNN_MFMA_CASE(16, 32)
+    KNN_MFMA_CASE(32, 4) KNN_MFMA_CASE(32, 8) KNN_MFMA_CASE(32, 16) KNN_MFMA_CASE(32, 32)
+    KNN_MFMA_CASE(64, 4) KNN_MFMA_CASE(64, 8) KNN_MFMA_CASE(64, 16) KNN_MFMA_CASE(64, 32)
+  }
   // experimental shapes, d <= 16 and r <= 16 only (selected through flgp_set_tuning)
   if (dpad == 16 && rcap == 16) {
     if (variant == 1) return launch_knn<16, 16, 2, 4, 8, 12>(KNN_ARGS);

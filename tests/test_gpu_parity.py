@@ -56,6 +56,31 @@ def test_knn_bit_exact(oracle, n, d, s, r):
     np.testing.assert_array_equal(api.KNN_cpp(X, U0, r)["ind_knn"], oi)   # output=FALSE path
 
 
+@pytest.mark.parametrize("mfma", [0, 1])
+def test_knn_both_kernels_bit_exact(oracle, mfma):
+    """The VALU kernel and the matrix-core kernel (v_mfma_f64_16x16x4 = a k-ascending FMA chain) are both
+    the oracle's arithmetic: forced one after the other over every padded dimension, ragged sizes and ties."""
+    from flgp_amd import _lib
+    L = _lib.lib()
+    try:
+        L.flgp_set_tuning(b"knn_mfma", mfma)
+        for n, d, s, r in [(777, 16, 333, 10), (300, 64, 140, 5), (200, 17, 50, 20), (513, 3, 128, 1), (100, 1, 10, 10),
+                           (4097, 7, 1025, 16), (130, 33, 70, 32)]:
+            X, U0, _ = make_case(n, d, s, r, seed=7 * n + d, with_sizes=False)
+            res = api.KNN_cpp(X, U0, r, output=True)
+            oi, od = oracle.knn(X, U0, r, output=True)
+            np.testing.assert_array_equal(res["ind_knn"], oi)
+            order = np.argsort(oi, axis=1, kind="stable")
+            np.testing.assert_array_equal(res["distances_sp"].data.reshape(n, r), np.take_along_axis(od, order, axis=1))
+        g = np.linspace(-1.0, 1.0, 5)     # exact ties: lower anchor index first
+        U = np.array([[a, b] for a in g for b in g] + [[0.0, 0.0], [1.0, 0.0]])
+        X = np.array([[0.0, 0.0], [0.5, 0.5], [3.0, -3.0], [-1.0, 2.0]])
+        for r in (1, 4, 9, 16):
+            np.testing.assert_array_equal(api.KNN_cpp(X, U, r)["ind_knn"], oracle.knn(X, U, r))
+    finally:
+        L.flgp_set_tuning(b"knn_mfma", -1)
+
+
 def test_knn_single_point(oracle):
     rng = np.random.default_rng(4)
     X = rng.normal(size=(1, 16)); U = rng.normal(size=(300, 16))
