@@ -978,6 +978,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
         double dm = 0.0;   // the last M must be the identity to rounding
         FLGP_TRY(dist_to_identity(Mm, &dm));
         ok = dm < 1e-13 * std::sqrt((double)b);
+        if (tuning("eig_verbose", 0) > 1) fprintf(stderr, "[flgp orth] delta=%.3e kmax=%d dm=%.2e %s\n", delta, kmax, dm, ok ? "ok" : "FAILED");
       }
       if (ok) {
         // Zc may live in JV or X2; the rotation needs diag(dinv) Z in W
@@ -1025,6 +1026,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
             ok = dm < 1e-9;
           }
         }
+        if (tuning("eig_verbose", 0) > 1) fprintf(stderr, "[flgp orth] scaled: delta=%.3e sigma=%.3e dm=%.2e %s\n", delta, sigma, dm, ok ? "ok" : "FAILED");
         if (ok) {
           double zn = 0.0;   // |Z - I|_F^2 + 1 >= 1/x_min: an upper bound of cond(S / sigma)
           FLGP_TRY(dist_to_identity(Zc, &zn));

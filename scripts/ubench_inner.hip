@@ -63,6 +63,67 @@ __global__ __launch_bounds__(256, 2) void staged(double *out, const double *__re
   out[blockIdx.x * 256 + tid] = sum;
 }
 
+
+// direct variant: the row-contiguous operand(s) go global -> LDS with global_load_lds_dwordx4 (no VGPR staging,
+// no ds_write): wave w fills k rows w, w+4, w+8, w+12 of the other buffer while this stage is multiplied.
+// BOTH = 1: both operands that way; BOTH = 0: A through registers (k-contiguous pattern), B direct.
+constexpr int GLDD = 146;   // 16-byte aligned rows
+template <int BOTH>
+__global__ __launch_bounds__(256, 2) void direct(double *out, const double *__restrict__ Ag, const double *__restrict__ Bg,
+                                                 int lda, int ldb, int stages) {
+  __shared__ __attribute__((aligned(16))) double As[2][GK * GLDD];
+  __shared__ __attribute__((aligned(16))) double Bs[2][GK * GLDD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64, fr = lane & 15, fk = lane >> 4;
+  for (int e = tid; e < GK * GLDD; e += 256) { As[0][e] = 1e-3 * e; As[1][e] = 2e-3 * e; Bs[0][e] = 1e-4 * e; Bs[1][e] = 3e-4 * e; }
+  __syncthreads();
+  d4 acc[4][4];
+  for (int mi = 0; mi < 4; ++mi) for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = d4{0, 0, 0, 0};
+  double ra[8];
+  for (int r = 0; r < 8; ++r) ra[r] = tid * 1e-5 + r;
+  const int row0 = (blockIdx.x % 32) * 128;
+  for (int s = 0; s < stages; ++s) {
+    const int cur = s & 1;
+    const double *A = As[cur], *B = Bs[cur];
+    const int k0 = ((s + 1) * 16) % 4096;
+    // next stage straight into the other buffer
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep) {
+      const int k = wave + 4 * rep;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Bg + (size_t)(k0 + k) * ldb + row0 + 2 * lane),
+                                       (__attribute__((address_space(3))) void *)&Bs[cur ^ 1][k * GLDD], 16, 0, 0);
+      if (BOTH)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(Ag + (size_t)(k0 + k) * lda + row0 + 2 * lane),
+                                         (__attribute__((address_space(3))) void *)&As[cur ^ 1][k * GLDD], 16, 0, 0);
+    }
+    if (!BOTH) {
+      { const int k = tid & 15, rbk = tid >> 4;
+#pragma unroll
+        for (int rep = 0; rep < 8; ++rep) As[cur ^ 1][k * GLDD + rbk + 16 * rep] = ra[rep]; }
+      { const int k = k0 + (tid & 15), rbk = tid >> 4;
+#pragma unroll
+        for (int rep = 0; rep < 8; ++rep) ra[rep] = Ag[(size_t)(row0 + rbk + 16 * rep) * lda + k]; }
+    }
+#pragma unroll
+    for (int kk = 0; kk < GK; kk += 4) {
+      double fa[4], fb[4];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) fa[mi] = A[(kk + fk) * GLDD + wr + mi * 16 + fr];
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) fb[ni] = B[(kk + fk) * GLDD + wc + ni * 16 + fr];
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's direct loads have landed
+    __syncthreads();
+  }
+  double sum = 0;
+  for (int mi = 0; mi < 4; ++mi) for (int ni = 0; ni < 4; ++ni) sum += acc[mi][ni][0] + acc[mi][ni][1] + acc[mi][ni][2] + acc[mi][ni][3];
+  out[blockIdx.x * 256 + tid] = sum;
+}
+
 template <bool M4, bool SYNC>
 __global__ __launch_bounds__(256, 2) void inner(double *out, int stages) {
   __shared__ double As[2][GK * GLD];
@@ -141,6 +202,9 @@ int main() {
     float b = time_it([&] { hipLaunchKernelGGL((staged<1>), dim3(grid), dim3(256), 0, 0, out, Ag, Bg, 4096, 4096, stages); });
     float c = time_it([&] { hipLaunchKernelGGL((staged<2>), dim3(grid), dim3(256), 0, 0, out, Ag, Bg, 4096, 4096, stages); });
     float d = time_it([&] { hipLaunchKernelGGL((staged<3>), dim3(grid), dim3(256), 0, 0, out, Ag, Bg, 4096, 4096, stages); });
+    float e = time_it([&] { hipLaunchKernelGGL((direct<0>), dim3(grid), dim3(256), 0, 0, out, Ag, Bg, 4096, 4096, stages); });
+    float f = time_it([&] { hipLaunchKernelGGL((direct<1>), dim3(grid), dim3(256), 0, 0, out, Ag, Bg, 4096, 4096, stages); });
+    printf("direct-to-LDS grid %d: B direct + A via registers %.1f TF | both direct %.1f TF\n", grid, fl / e * 1e-9, fl / f * 1e-9);
     printf("staged grid %d: compute only %.1f TF | + LDS stores %.1f TF | + global loads %.1f TF | + both %.1f TF\n", grid,
            fl / a * 1e-9, fl / b * 1e-9, fl / c * 1e-9, fl / d * 1e-9);
   }
