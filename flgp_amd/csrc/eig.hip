@@ -1203,7 +1203,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
       // the other stream: T = W Th W^T
       FLGP_HIP(hipStreamWaitEvent(side.st, side.ev, 0));
       FLGP_TRY(jacobi_refine(side.st, w.T, b, K, w, lam, &sweeps,
-                             std::max(1, (rmax_prev > 3e-3 ? 3 : (rmax_prev > 1e-6 ? 2 : 1)) - tuning("eig_refine_minus", 0))));
+                             std::max(1, (rmax_prev > 1e-4 * tuning("eig_refine3_above_e4", 2000) ? 3 : (rmax_prev > 1e-8 * tuning("eig_refine2_above_e8", 100) ? 2 : 1)) - tuning("eig_refine_minus", 0))));
       FLGP_TRY(sorted_basis(side.st, lam, nullptr, b, b, w, order));   // synchronises the side stream: W is ready
       for (int j = 0; j < b; ++j) theta[j] = lam[order[j]];
       // the two buffers of {Q, F1, F2} that do not hold the filtered block take A and B
@@ -1238,7 +1238,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
           FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps, tuning("eig_sweeps_it2", 3), 1e6));
         else
           FLGP_TRY(jacobi_refine(st, w.T, b, K, w, lam, &sweeps,
-                                 std::max(1, (rmax_prev > 3e-3 ? 3 : (rmax_prev > 1e-6 ? 2 : 1)) - tuning("eig_refine_minus", 0))));
+                                 std::max(1, (rmax_prev > 1e-4 * tuning("eig_refine3_above_e4", 2000) ? 3 : (rmax_prev > 1e-8 * tuning("eig_refine2_above_e8", 100) ? 2 : 1)) - tuning("eig_refine_minus", 0))));
         FLGP_TRY(sorted_basis(st, lam, nullptr, b, b, w, order));
         for (int j = 0; j < b; ++j) theta[j] = lam[order[j]];
         FLGP_TRY(rotate(Q, w.W, A));   // A = Ritz vectors
