@@ -66,11 +66,23 @@ inline int check_launch(const char *what) {
   return FLGP_OK;
 }
 
+// Optional block-sparse reduction for gemm_launch: per 128-wide tile of one operand (rows of A if on_a, columns
+// of B otherwise; the last tile slid back inside like the kernel's edge tiles) the list of 16-deep k stages that
+// hold any of its nonzeros.  Stages not listed are skipped.
+struct GemmStageList {
+  const int *klist;     // [tiles][ld] stage numbers, ascending
+  const int *nk;        // [tiles] entries per tile
+  int ld;
+  bool on_a;
+  long total_stages;    // sum of nk
+  int max_stages;       // max of nk
+};
+
 // C(i,j) = alpha * sum_k A(i,k) B(k,j) + beta * E(i,j) + gamma * E2(i,j)   (gemm.hip)
 int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double *A, long a_is, long a_ks,
                 const double *B, long b_ks, long b_js, double beta, const double *E, long e_is, long e_js,
                 double *C, long c_is, long c_js, double *work, size_t work_elems, double gamma,
-                const double *E2);
+                const double *E2, const GemmStageList *sl = nullptr);
 
 
 // Register-resident LAE kernels (lae_reg*.hip).  Returns FLGP_LAE_REG_NONE when no kernel of the family

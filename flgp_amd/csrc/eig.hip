@@ -216,6 +216,7 @@ __global__ __launch_bounds__(1024) void jac_round_kernel(double *__restrict__ B,
 // the slow direction on CDNA4), which is what made the scalar version (jac_round_kernel) slow.
 // ------------------------------------------------------------------------------------------
 typedef double jd4 __attribute__((ext_vector_type(4)));
+typedef double d2v __attribute__((ext_vector_type(2)));
 
 template <int NLOC>
 __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B, double *__restrict__ V, int b,
@@ -692,6 +693,331 @@ static size_t eig_gemm_ws_elems(int s, int b) {
   return a > c ? a : c;
 }
 
+// ------------------------------------------------------------------------------------------
+// Block-sparse products with G.
+//
+// G = A^T A couples two anchors only if some point has both among its r nearest: at C3 (s = 5000, r = 10)
+// 5 % of G is non-zero, 248 entries per row.  In the order the anchors arrive in that is useless to a tiled
+// GEMM (98 % of the 16 x 128 operand blocks hold something), but G is the weight matrix of a neighbourhood
+// graph with cluster / manifold structure, so a symmetric permutation concentrates it: after the ordering
+// below 10 % of the blocks hold 98 % of the non-zeros (scripts/exp_gorder.py).  The filter's products then
+// run as  (dense blocks: tiled MFMA GEMM over the listed k stages only)  +  (the scattered rest: a small
+// CSR product),  on the permuted matrix P G P^T; the eigenvectors are permuted back at the end.  Nothing
+// here can change a result beyond rounding: the ordering only decides how much work is skipped.
+//
+// Ordering, from G alone (no coordinates): p seed anchors, three hops of diffusion G^3 e_seed (one GEMM per
+// hop), every anchor joins the seed it received most from, two rounds of label smoothing (take the label
+// that carries most weight among the neighbours), then the clusters are chained greedily by their mutual
+// weight so that related clusters sit next to each other.
+// ------------------------------------------------------------------------------------------
+constexpr int BS_SEEDS = 64;     // seed anchors / clusters of the ordering
+constexpr int BS_DENSE = 32;     // a 16 x 128 block with at least this many non-zeros goes to the tiled GEMM
+
+__global__ void bs_seed_kernel(double *__restrict__ E, int s, int p) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)s * p) return;
+  const int i = (int)(e % s), q = (int)(e / s);
+  E[e] = (i == (int)(((long)q * s) / p)) ? 1.0 : 0.0;
+}
+// label = column of the largest entry in row i (lowest column on ties; p if the row is all zero)
+__global__ void bs_argmax_kernel(const double *__restrict__ E, int s, int p, int *__restrict__ lab) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= s) return;
+  double best = 0.0; int bq = p;
+  for (int q = 0; q < p; ++q) {
+    const double v = E[(size_t)q * s + i];
+    if (v > best) { best = v; bq = q; }
+  }
+  lab[i] = bq;
+}
+__global__ void bs_onehot_kernel(const int *__restrict__ lab, int s, int p, double *__restrict__ OH) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)s * p) return;
+  const int i = (int)(e % s), q = (int)(e / s);
+  OH[e] = (lab[i] == q) ? 1.0 : 0.0;
+}
+// Gp(i', k') = G(perm[i'], perm[k'])
+__global__ void bs_permute_kernel(const double *__restrict__ G, int ldg, int s, const int *__restrict__ perm,
+                                  double *__restrict__ Gp) {
+  const int kp = blockIdx.y;
+  const int ip = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ip >= s) return;
+  Gp[(size_t)kp * s + ip] = G[(size_t)perm[kp] * ldg + perm[ip]];
+}
+// non-zeros of the 16 x 128 block (k stage, i tile) of Gp; Gp(k, i) at k + i*s (symmetric)
+__global__ __launch_bounds__(128) void bs_count_kernel(const double *__restrict__ Gp, int s, int nstage,
+                                                       int *__restrict__ cnt) {
+  const int stage = blockIdx.x, tile = blockIdx.y;
+  const int i = tile * 128 + threadIdx.x;
+  int c = 0;
+  if (i < s) {
+    const double *col = Gp + (size_t)i * s + (size_t)stage * 16;
+    for (int k = 0; k < 16; ++k)
+      if (stage * 16 + k < s && col[k] != 0.0) ++c;
+  }
+  __shared__ int red[128];
+  red[threadIdx.x] = c;
+  __syncthreads();
+  for (int off = 64; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) cnt[tile * nstage + stage] = red[0];
+}
+// the rest: non-zeros of row i that sit in blocks the GEMM skips.  One wave per row, column i of Gp read
+// contiguously (symmetry); count pass (fill == 0) and fill pass (entries in ascending k).
+__global__ __launch_bounds__(64) void bs_remainder_kernel(const double *__restrict__ Gp, int s, int nstage,
+                                                          const unsigned char *__restrict__ dense,
+                                                          const int *__restrict__ rptr, int *__restrict__ rcnt,
+                                                          int *__restrict__ rcol, double *__restrict__ rval, int fill) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  const unsigned char *dn = dense + (size_t)(i / 128) * nstage;
+  const double *col = Gp + (size_t)i * s;
+  int n = 0;
+  const int base = fill ? rptr[i] : 0;
+  for (int k0 = 0; k0 < s; k0 += 64) {
+    const int k = k0 + lane;
+    const double v = (k < s) ? col[k] : 0.0;
+    const bool take = (k < s) && v != 0.0 && !dn[k >> 4];
+    const unsigned long long m = __ballot(take);
+    if (fill && take) {
+      const int o = base + n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
+      rcol[o] = k;
+      rval[o] = v;
+    }
+    n += __builtin_popcountll(m);
+  }
+  if (!fill && lane == 0) rcnt[i] = n;
+}
+// out(c, i) += alpha * sum_e rval[e] * X(c, rcol[e]) for the remainder entries e of row i; X, out are b x s, c
+// contiguous.  One workgroup per row: its four waves split the row's entries (a hub anchor can have a couple of
+// hundred: taken by one wave, that row alone would set the kernel's run time), every lane owns four adjacent
+// columns and keeps eight 32-byte row loads in flight; the four partial sums are added in wave order.
+__global__ __launch_bounds__(256) void bs_spmm_kernel(const int *__restrict__ rptr, const int *__restrict__ rcol,
+                                                      const double *__restrict__ rval, const double *__restrict__ Xt, int s,
+                                                      int b, double alpha, double *__restrict__ out) {
+  __shared__ double part[3][256];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = blockIdx.x;
+  const int e0 = rptr[i], e1 = rptr[i + 1];
+  if (e0 == e1) return;     // uniform over the workgroup
+  const int n = e1 - e0;
+  const int q = (n <= 8) ? n : (n + 3) / 4;            // short rows: wave 0 alone
+  const int my0 = e0 + wave * q, my1 = (my0 + q < e1) ? my0 + q : e1;
+  for (int c0 = 0; c0 < b; c0 += 256) {
+    const int c = c0 + 4 * lane;
+    const bool okc = c + 3 < b;            // b is a multiple of 16: a lane's four columns are all in or all out
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (int eb = my0; eb < my1; eb += 64) {
+      const int ne = (my1 - eb < 64) ? my1 - eb : 64;
+      const int kc = (lane < ne) ? rcol[eb + lane] : 0;
+      const double vc = (lane < ne) ? rval[eb + lane] : 0.0;
+      for (int j = 0; j < ne; j += 8) {
+        d2v xa[8], xb[8];
+        double vv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int jj = (j + u < ne) ? j + u : j;
+          const int k = __shfl(kc, jj, 64);
+          vv[u] = (j + u < ne) ? __shfl(vc, jj, 64) : 0.0;
+          const d2v *x = (const d2v *)(Xt + (size_t)k * b + (okc ? c : 0));
+          xa[u] = x[0];
+          xb[u] = x[1];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          a0 += vv[u] * xa[u][0]; a1 += vv[u] * xa[u][1]; a2 += vv[u] * xb[u][0]; a3 += vv[u] * xb[u][1];
+        }
+      }
+    }
+    if (n > 8) {
+      if (wave > 0) {
+        part[wave - 1][4 * lane + 0] = a0; part[wave - 1][4 * lane + 1] = a1;
+        part[wave - 1][4 * lane + 2] = a2; part[wave - 1][4 * lane + 3] = a3;
+      }
+      __syncthreads();
+      if (wave == 0) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+          a0 += part[w][4 * lane + 0]; a1 += part[w][4 * lane + 1]; a2 += part[w][4 * lane + 2]; a3 += part[w][4 * lane + 3];
+        }
+      }
+      __syncthreads();
+    }
+    if (wave == 0 && okc) {
+      double *o = out + (size_t)i * b + c;
+      o[0] += alpha * a0; o[1] += alpha * a1; o[2] += alpha * a2; o[3] += alpha * a3;
+    }
+  }
+}
+// tiled transpose: in is R x C with element (r, c) at r + c*R; out(c, r) at c + r*C
+__global__ void bs_transpose_kernel(const double *__restrict__ in, int R, int C, double *__restrict__ out) {
+  __shared__ double t[32][33];
+  const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 256 threads: ty 0..7
+  for (int cc = ty; cc < 32; cc += 8) {
+    const int r = r0 + tx, c = c0 + cc;
+    t[cc][tx] = (r < R && c < C) ? in[(size_t)c * R + r] : 0.0;
+  }
+  __syncthreads();
+  for (int rr = ty; rr < 32; rr += 8) {
+    const int r = r0 + rr, c = c0 + tx;
+    if (r < R && c < C) out[(size_t)r * C + c] = t[tx][rr];
+  }
+}
+// V(perm[i'], k) = R(i', k)
+__global__ void bs_unpermute_kernel(const double *__restrict__ R, int s, int K, const int *__restrict__ perm,
+                                    double *__restrict__ V, int ldv) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)s * K) return;
+  const int ip = (int)(e % s), k = (int)(e / s);
+  V[(size_t)k * ldv + perm[ip]] = R[e];
+}
+
+struct BlockSparseG {
+  bool on = false;
+  double *Gp = nullptr;
+  int *perm = nullptr;
+  int *klist = nullptr, *nk = nullptr;
+  int ntile = 0, nstage = 0;
+  long total = 0;
+  int maxn = 0;
+  int *rptr = nullptr, *rcol = nullptr;
+  double *rval = nullptr;
+  int rnnz = 0;
+  double *T[3] = {nullptr, nullptr, nullptr};   // b x s blocks of the transposed filter
+  double dense_frac = 1.0;
+};
+
+static size_t bs_workspace_bytes(int s, int b) {
+  const int ntile = (s + 127) / 128, nstage = (s + 15) / 16;
+  size_t tot = align_up(sizeof(double) * (size_t)s * s);                         // Gp
+  tot += 3 * align_up(sizeof(double) * (size_t)s * BS_SEEDS);                     // diffusion blocks
+  tot += align_up(sizeof(double) * (size_t)BS_SEEDS * BS_SEEDS);
+  tot += 2 * align_up(sizeof(int) * (size_t)s);                                   // labels, perm
+  tot += 2 * align_up(sizeof(int) * (size_t)ntile * nstage) + align_up(sizeof(int) * (size_t)ntile);   // counts, klist, nk
+  tot += align_up((size_t)ntile * nstage);                                        // dense flags
+  tot += 2 * align_up(sizeof(int) * (size_t)(s + 1));                             // rptr, rcnt
+  tot += align_up(sizeof(int) * (size_t)ntile * nstage * BS_DENSE) + align_up(sizeof(double) * (size_t)ntile * nstage * BS_DENSE);
+  tot += 3 * align_up(sizeof(double) * (size_t)s * b);                            // transposed blocks
+  return tot;
+}
+
+// Builds the permuted copy, the stage lists and the remainder; leaves bs.on = false when the matrix does
+// not concentrate (then the solver multiplies with the dense G as before).  Synchronises the stream.
+struct BsScratch {
+  double *E0, *E1, *E2, *C;
+  int *lab, *cnt, *rcnt;
+  unsigned char *dense;
+};
+static int bs_setup(hipStream_t st, const double *dG, int ldg, int s, int b, double *gemm_ws, size_t gemm_ws_elems,
+                    BlockSparseG &bs, BsScratch &sc) {
+  const int p = BS_SEEDS;
+  const int ntile = bs.ntile, nstage = bs.nstage;
+  const long sp = (long)s * p;
+  auto hop = [&](const double *in, double *out) {   // out = G in   (s x p)
+    return gemm_launch(st, s, p, s, 1.0, dG, 1, ldg, in, 1, s, 0.0, nullptr, 0, 0, out, 1, s, gemm_ws, gemm_ws_elems, 0.0,
+                       nullptr);
+  };
+  hipLaunchKernelGGL(bs_seed_kernel, dim3(ceil_div(sp, 256)), dim3(256), 0, st, sc.E0, s, p);
+  FLGP_TRY(check_launch("bs_seed_kernel"));
+  FLGP_TRY(hop(sc.E0, sc.E1));
+  FLGP_TRY(hop(sc.E1, sc.E2));
+  FLGP_TRY(hop(sc.E2, sc.E1));
+  hipLaunchKernelGGL(bs_argmax_kernel, dim3(ceil_div(s, 256)), dim3(256), 0, st, sc.E1, s, p, sc.lab);
+  for (int round = 0; round < 2; ++round) {     // label smoothing
+    hipLaunchKernelGGL(bs_onehot_kernel, dim3(ceil_div(sp, 256)), dim3(256), 0, st, sc.lab, s, p, sc.E0);
+    FLGP_TRY(hop(sc.E0, sc.E1));
+    hipLaunchKernelGGL(bs_argmax_kernel, dim3(ceil_div(s, 256)), dim3(256), 0, st, sc.E1, s, p, sc.lab);
+  }
+  // cluster-to-cluster weights C = OH^T G OH
+  hipLaunchKernelGGL(bs_onehot_kernel, dim3(ceil_div(sp, 256)), dim3(256), 0, st, sc.lab, s, p, sc.E0);
+  FLGP_TRY(hop(sc.E0, sc.E1));
+  FLGP_TRY(gemm_launch(st, p, p, s, 1.0, sc.E0, s, 1, sc.E1, 1, s, 0.0, nullptr, 0, 0, sc.C, 1, p, gemm_ws, gemm_ws_elems, 0.0,
+                       nullptr));
+  FLGP_TRY(check_launch("bs ordering"));
+  std::vector<int> lab(s);
+  std::vector<double> C((size_t)p * p);
+  FLGP_HIP(hipMemcpyAsync(lab.data(), sc.lab, sizeof(int) * s, hipMemcpyDeviceToHost, st));
+  FLGP_HIP(hipMemcpyAsync(C.data(), sc.C, sizeof(double) * p * p, hipMemcpyDeviceToHost, st));
+  FLGP_HIP(hipStreamSynchronize(st));
+  // chain the clusters: start at the heaviest, always continue with the unused cluster most strongly tied to the last
+  std::vector<int> order, rank(p + 1, p);
+  std::vector<char> used(p, 0);
+  {
+    int start = 0; double best = -1.0;
+    for (int q = 0; q < p; ++q) {
+      double w = 0.0;
+      for (int q2 = 0; q2 < p; ++q2) if (q2 != q) w += std::fabs(C[(size_t)q2 * p + q]);
+      if (w > best) { best = w; start = q; }
+    }
+    order.push_back(start); used[start] = 1;
+    while ((int)order.size() < p) {
+      const int cur = order.back();
+      int nxt = -1; double bw = -1.0;
+      for (int q = 0; q < p; ++q)
+        if (!used[q] && std::fabs(C[(size_t)q * p + cur]) > bw) { bw = std::fabs(C[(size_t)q * p + cur]); nxt = q; }
+      order.push_back(nxt); used[nxt] = 1;
+    }
+    for (int q = 0; q < p; ++q) rank[order[q]] = q;   // label p (isolated anchors) keeps rank p: last
+  }
+  std::vector<int> perm(s), start(p + 2, 0);
+  for (int i = 0; i < s; ++i) ++start[rank[lab[i]] + 1];
+  for (int q = 0; q <= p; ++q) start[q + 1] += start[q];
+  for (int i = 0; i < s; ++i) perm[start[rank[lab[i]]]++] = i;   // stable counting sort by cluster rank
+  FLGP_HIP(hipMemcpyAsync(bs.perm, perm.data(), sizeof(int) * s, hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(bs_permute_kernel, dim3(ceil_div(s, 256), s), dim3(256), 0, st, dG, ldg, s, bs.perm, bs.Gp);
+  hipLaunchKernelGGL(bs_count_kernel, dim3(nstage, ntile), dim3(128), 0, st, bs.Gp, s, nstage, sc.cnt);
+  FLGP_TRY(check_launch("bs_count_kernel"));
+  std::vector<int> cnt((size_t)ntile * nstage);
+  FLGP_HIP(hipMemcpyAsync(cnt.data(), sc.cnt, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, st));
+  FLGP_HIP(hipStreamSynchronize(st));   // also keeps `perm` alive until its copy is done
+  std::vector<int> klist((size_t)ntile * nstage), nk(ntile, 0);
+  std::vector<unsigned char> dense((size_t)ntile * nstage, 0);
+  long total = 0, nblocks = 0, rem_bound = 0;
+  int maxn = 0;
+  for (int t = 0; t < ntile; ++t) {
+    for (int g = 0; g < nstage; ++g) {
+      const int c = cnt[(size_t)t * nstage + g];
+      ++nblocks;
+      if (c >= BS_DENSE) { klist[(size_t)t * nstage + nk[t]++] = g; dense[(size_t)t * nstage + g] = 1; }
+      else rem_bound += c;
+    }
+    total += nk[t];
+    maxn = std::max(maxn, nk[t]);
+  }
+  bs.total = total; bs.maxn = maxn;
+  bs.dense_frac = (double)total / (double)nblocks;
+  if (tuning("eig_verbose", 0))
+    fprintf(stderr, "[flgp eig] block-sparse G: %.1f %% of the 16x128 blocks kept for the tiled GEMM (max %d of %d stages per tile), %ld scattered non-zeros\n",
+            100.0 * bs.dense_frac, maxn, nstage, rem_bound);
+  if (bs.dense_frac > 0.01 * tuning("eig_bs_max_pct", 50)) { bs.on = false; return FLGP_OK; }
+  FLGP_HIP(hipMemcpyAsync(bs.klist, klist.data(), sizeof(int) * klist.size(), hipMemcpyHostToDevice, st));
+  FLGP_HIP(hipMemcpyAsync(bs.nk, nk.data(), sizeof(int) * ntile, hipMemcpyHostToDevice, st));
+  FLGP_HIP(hipMemcpyAsync(sc.dense, dense.data(), dense.size(), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(bs_remainder_kernel, dim3(s), dim3(64), 0, st, bs.Gp, s, nstage, sc.dense, nullptr, sc.rcnt, nullptr,
+                     nullptr, 0);
+  FLGP_TRY(check_launch("bs_remainder_kernel"));
+  std::vector<int> rcnt(s), rptr(s + 1, 0);
+  FLGP_HIP(hipMemcpyAsync(rcnt.data(), sc.rcnt, sizeof(int) * s, hipMemcpyDeviceToHost, st));
+  FLGP_HIP(hipStreamSynchronize(st));
+  for (int i = 0; i < s; ++i) rptr[i + 1] = rptr[i] + rcnt[i];
+  bs.rnnz = rptr[s];
+  if (tuning("eig_verbose", 0)) {
+    int mx = 0, over64 = 0;
+    for (int i = 0; i < s; ++i) { mx = std::max(mx, rcnt[i]); over64 += rcnt[i] > 64; }
+    fprintf(stderr, "[flgp eig] remainder: %d entries, longest row %d, rows over 64: %d\n", bs.rnnz, mx, over64);
+  }
+  FLGP_HIP(hipMemcpyAsync(bs.rptr, rptr.data(), sizeof(int) * (s + 1), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(bs_remainder_kernel, dim3(s), dim3(64), 0, st, bs.Gp, s, nstage, sc.dense, bs.rptr, sc.rcnt, bs.rcol,
+                     bs.rval, 1);
+  FLGP_TRY(check_launch("bs_remainder_kernel"));
+  FLGP_HIP(hipStreamSynchronize(st));
+  bs.on = true;
+  (void)b;
+  return FLGP_OK;
+}
+
 static size_t eig_workspace_bytes(int s, int K) {
   const bool dense = eig_use_dense(s, K);
   const int b = dense ? s : eig_block_size(s, K);
@@ -701,6 +1027,7 @@ static size_t eig_workspace_bytes(int s, int K) {
   tot += 4 * align_up(sizeof(double) * (size_t)b);
   tot += align_up(sizeof(int) * (size_t)b) + align_up(sizeof(int) * 16);
   if (!dense) tot += align_up(sizeof(double) * eig_gemm_ws_elems(s, b));
+  if (!dense && s >= 1024) tot += bs_workspace_bytes(s, b);
   return tot + 1024;
 }
 
@@ -874,6 +1201,28 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   w.perm = (int *)take(sizeof(int) * b); w.flags = (int *)take(sizeof(int) * 16);
   w.gemm_ws_elems = dense ? 0 : eig_gemm_ws_elems(s, b);
   w.gemm_ws = dense ? nullptr : (double *)take(sizeof(double) * w.gemm_ws_elems);
+  BlockSparseG bs;
+  if (!dense && s >= 1024 && tuning("eig_blocksparse", 1)) {
+    bs.ntile = (s + 127) / 128; bs.nstage = (s + 15) / 16;
+    BsScratch sc;
+    bs.Gp = (double *)take(sizeof(double) * (size_t)s * s);
+    sc.E0 = (double *)take(sizeof(double) * (size_t)s * BS_SEEDS);
+    sc.E1 = (double *)take(sizeof(double) * (size_t)s * BS_SEEDS);
+    sc.E2 = (double *)take(sizeof(double) * (size_t)s * BS_SEEDS);
+    sc.C = (double *)take(sizeof(double) * (size_t)BS_SEEDS * BS_SEEDS);
+    sc.lab = (int *)take(sizeof(int) * (size_t)s);
+    bs.perm = (int *)take(sizeof(int) * (size_t)s);
+    sc.cnt = (int *)take(sizeof(int) * (size_t)bs.ntile * bs.nstage);
+    bs.klist = (int *)take(sizeof(int) * (size_t)bs.ntile * bs.nstage);
+    bs.nk = (int *)take(sizeof(int) * (size_t)bs.ntile);
+    sc.dense = (unsigned char *)take((size_t)bs.ntile * bs.nstage);
+    bs.rptr = (int *)take(sizeof(int) * (size_t)(s + 1));
+    sc.rcnt = (int *)take(sizeof(int) * (size_t)(s + 1));
+    bs.rcol = (int *)take(sizeof(int) * (size_t)bs.ntile * bs.nstage * BS_DENSE);
+    bs.rval = (double *)take(sizeof(double) * (size_t)bs.ntile * bs.nstage * BS_DENSE);
+    for (int q = 0; q < 3; ++q) bs.T[q] = (double *)take(sizeof(double) * (size_t)s * b);
+    FLGP_TRY(bs_setup(st, dG, ldg, s, b, w.gemm_ws, w.gemm_ws_elems, bs, sc));
+  }
 
   std::vector<double> lam;
   std::vector<int> order;
@@ -900,6 +1249,29 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     return gemm_launch(st, s, b, s, alpha, dG, 1, ldg, Xin, 1, s, beta, E, 1, s, out, 1, s, w.gemm_ws,
                        w.gemm_ws_elems, gamma, E2);
   };
+  // ---- block-sparse products (bs.on): blocks live transposed (b x s, the b values of one row contiguous) while
+  //      the filter runs, so that both the tiled GEMM (over the listed k stages of P G P^T) and the CSR remainder
+  //      read and write whole 8b-byte rows
+  auto to_t = [&](const double *in, double *out_t) {     // s x b  ->  b x s
+    hipLaunchKernelGGL(bs_transpose_kernel, dim3(ceil_div(s, 32), ceil_div(b, 32)), dim3(256), 0, st, in, s, b, out_t);
+    return check_launch("bs_transpose_kernel");
+  };
+  auto from_t = [&](const double *in_t, double *out) {   // b x s  ->  s x b
+    hipLaunchKernelGGL(bs_transpose_kernel, dim3(ceil_div(b, 32), ceil_div(s, 32)), dim3(256), 0, st, in_t, b, s, out);
+    return check_launch("bs_transpose_kernel");
+  };
+  auto gemmG_t = [&](const double *Xt, double alpha, double beta, const double *Et, double gamma, const double *E2t,
+                     double *out_t) -> int {   // out_t = alpha X_t G' + beta E_t + gamma E2_t   (b x s)
+    GemmStageList sl{bs.klist, bs.nk, bs.nstage, false, bs.total, bs.maxn};
+    FLGP_TRY(gemm_launch(st, b, s, s, alpha, Xt, 1, b, bs.Gp, s, 1, beta, Et, 1, b, out_t, 1, b, w.gemm_ws, w.gemm_ws_elems,
+                         gamma, E2t, &sl));
+    if (bs.rnnz > 0) {
+      hipLaunchKernelGGL(bs_spmm_kernel, dim3(s), dim3(256), 0, st, bs.rptr, bs.rcol, bs.rval, Xt, s, b, alpha, out_t);
+      FLGP_TRY(check_launch("bs_spmm_kernel"));
+    }
+    return FLGP_OK;
+  };
+  const double *t_q = nullptr, *t_z = nullptr;   // blocks whose transposes currently sit in bs.T[0], bs.T[1]
   auto gram_small = [&](const double *Xa, const double *Xb, double *out) {  // out = Xa^T Xb   (b x b)
     return gemm_launch(st, b, b, s, 1.0, Xa, s, 1, Xb, 1, s, 0.0, nullptr, 0, 0, out, 1, b, w.gemm_ws,
                        w.gemm_ws_elems, 0.0, nullptr);
@@ -1123,6 +1495,29 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   auto apply_filter = [&](const FilterPlan &fp, double *A, const double *B, double *f1, double *f2, double **cur_out,
                           double **spare_out) -> int {
     double sigma = fp.sigma1;
+    if (bs.on) {
+      // the recurrence on transposed blocks; A and B are left alone, the result lands in f1
+      if (!(t_q == A && t_z == B)) {
+        FLGP_TRY(to_t(A, bs.T[0]));
+        FLGP_TRY(to_t(B, bs.T[1]));
+      }
+      t_q = nullptr; t_z = nullptr;
+      double *prev = bs.T[0], *cur = bs.T[2], *next = bs.T[1];
+      hipLaunchKernelGGL(eig_axpby_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, st, fp.sigma1 / fp.e, bs.T[1],
+                         -fp.sigma1 * fp.c / fp.e, bs.T[0], cur, tot);
+      FLGP_TRY(check_launch("eig_axpby_kernel"));
+      for (int deg = 2; deg <= fp.m; ++deg) {
+        const double sn = 1.0 / (2.0 / fp.sigma1 - sigma);
+        FLGP_TRY(gemmG_t(cur, 2.0 * sn / fp.e, -2.0 * sn * fp.c / fp.e, cur, -sigma * sn, prev, next));
+        ++gprods;
+        double *t3 = prev; prev = cur; cur = next; next = t3;
+        sigma = sn;
+      }
+      FLGP_TRY(from_t(cur, f1));
+      *cur_out = f1;
+      *spare_out = f2;
+      return FLGP_OK;
+    }
     // degree 1: Y = (sigma1/e) (G A - c A) = (sigma1/e) (B - c A), into a free buffer
     double *prev = A, *cur = f1, *next = f2;
     hipLaunchKernelGGL(eig_axpby_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, st, fp.sigma1 / fp.e, B,
@@ -1174,7 +1569,14 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     double *Z = F[0];
     double *A, *B, *free1, *free2;     // Ritz vectors, G * Ritz vectors, two free s x b buffers
     double *cur = nullptr, *spare = nullptr;   // filtered block; a buffer that is free after the filter
-    FLGP_TRY(gemmG(Q, 1.0, 0.0, nullptr, 0.0, nullptr, Z));
+    if (bs.on) {
+      FLGP_TRY(to_t(Q, bs.T[0]));
+      FLGP_TRY(gemmG_t(bs.T[0], 1.0, 0.0, nullptr, 0.0, nullptr, bs.T[1]));
+      FLGP_TRY(from_t(bs.T[1], Z));
+      t_q = Q; t_z = Z;
+    } else {
+      FLGP_TRY(gemmG(Q, 1.0, 0.0, nullptr, 0.0, nullptr, Z));
+    }
     ++gprods;
     // Rayleigh-Ritz may be skipped on some late iterations (rr_every > 1): the block is then used as it
     // is (its columns are the previous Ritz vectors, filtered, cleaned and orthonormalised: still ordered
@@ -1287,8 +1689,13 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     return FLGP_ERR_NOCONV;
   }
   FLGP_HIP(hipMemcpyAsync(d_values, theta.data(), sizeof(double) * K, hipMemcpyHostToDevice, st));
-  FLGP_HIP(hipMemcpy2DAsync(dV, sizeof(double) * ldv, result, sizeof(double) * s, sizeof(double) * s, K,
-                            hipMemcpyDeviceToDevice, st));
+  if (bs.on) {   // the solver worked on P G P^T: rows back to the caller's anchor order
+    hipLaunchKernelGGL(bs_unpermute_kernel, dim3(ceil_div((long)s * K, 256)), dim3(256), 0, st, result, s, K, bs.perm, dV, ldv);
+    FLGP_TRY(check_launch("bs_unpermute_kernel"));
+  } else {
+    FLGP_HIP(hipMemcpy2DAsync(dV, sizeof(double) * ldv, result, sizeof(double) * s, sizeof(double) * s, K,
+                              hipMemcpyDeviceToDevice, st));
+  }
   FLGP_HIP(hipStreamSynchronize(st));
   return FLGP_OK;
 }

@@ -43,6 +43,11 @@ struct GemmArgs {
   int shift_edges;                    // edge tiles slide back inside the matrix (they recompute a few columns / rows)
   int ksplit_len;                     // k range per blockIdx.z (multiple of GK); partials when gridDim.z > 1
   double *part;                       // [z][M][N] row-major partials
+  // block-sparse reduction (optional): only the k stages listed for this tile are multiplied.  klist holds, per
+  // tile of the sparse operand (row tiles when klist_on_rows, else column tiles), nk[tile] stage numbers
+  // (k0 = stage * GK) at klist[tile * klist_ld ...]; the gridDim.z blocks of a tile share its list evenly.
+  const int *klist, *nk;
+  int klist_ld, klist_on_rows;
 };
 
 // ---- operand staging: a 128(rows) x 16(k) tile goes global -> 8 registers per thread -> LDS [k][row].
@@ -202,9 +207,23 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     if (col0 + GB > g.N && g.N >= GB) col0 = g.N - GB;
   }
 
-  const int kbeg = blockIdx.z * g.ksplit_len;
-  int kend = kbeg + g.ksplit_len;
-  if (kend > g.Kd) kend = g.Kd;
+  // the k stages of this block: a contiguous range (dense), or its share of the tile's stage list (block-sparse)
+  int kbeg = 0, kend = g.Kd, ns;
+  const int *kl = nullptr;
+  if (g.klist) {
+    const int t = g.klist_on_rows ? tm : tn;
+    const int L = g.nk[t];
+    const int s0 = (int)((long)blockIdx.z * L / gridDim.z), s1 = (int)((long)(blockIdx.z + 1) * L / gridDim.z);
+    kl = g.klist + (size_t)t * g.klist_ld + s0;
+    ns = s1 - s0;
+  } else {
+    kbeg = blockIdx.z * g.ksplit_len;
+    kend = kbeg + g.ksplit_len;
+    if (kend > g.Kd) kend = g.Kd;
+    ns = (kend - kbeg + GK - 1) / GK;
+    if (ns < 0) ns = 0;
+  }
+  auto kof = [&](int si) { return kl ? kl[si] * GK : kbeg + si * GK; };
 
   const Operand oa = make_operand(g.A, g.a_is, g.a_ks, row0, g.M, tid);
   const Operand ob = make_operand(g.B, g.b_js, g.b_ks, col0, g.N, tid);
@@ -215,32 +234,35 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
 
   double ra[8], rb[8];
-  {
-    const bool f0 = kbeg + GK <= kend;
-    stage_load(ra, oa, kbeg, kend, f0, tid);
-    stage_load(rb, ob, kbeg, kend, f0, tid);
+  if (ns > 0) {
+    const int k0 = kof(0);
+    const bool f0 = k0 + GK <= kend;
+    stage_load(ra, oa, k0, kend, f0, tid);
+    stage_load(rb, ob, k0, kend, f0, tid);
     stage_store(ra, As2[0], oa, f0, tid);
     stage_store(rb, Bs2[0], ob, f0, tid);
-    if (kbeg + GK < kend) {
-      const bool f1 = kbeg + 2 * GK <= kend;
-      stage_load(ra, oa, kbeg + GK, kend, f1, tid);
-      stage_load(rb, ob, kbeg + GK, kend, f1, tid);
+    if (ns > 1) {
+      const int k1 = kof(1);
+      const bool f1 = k1 + GK <= kend;
+      stage_load(ra, oa, k1, kend, f1, tid);
+      stage_load(rb, ob, k1, kend, f1, tid);
     }
   }
   __syncthreads();
 
   const int fr = lane & 15, fk = lane >> 4;
   int cur = 0;
-  for (int k0 = kbeg; k0 < kend; k0 += GK, cur ^= 1) {
+  for (int si = 0; si < ns; ++si, cur ^= 1) {
     const double *As = As2[cur], *Bs = Bs2[cur];
-    if (k0 + GK < kend) {      // stage s+1 goes into the other buffer (last read before the previous barrier)
-      const bool f1 = k0 + 2 * GK <= kend;
+    if (si + 1 < ns) {      // stage s+1 goes into the other buffer (last read before the previous barrier)
+      const bool f1 = kof(si + 1) + GK <= kend;
       stage_store(ra, As2[cur ^ 1], oa, f1, tid);
       stage_store(rb, Bs2[cur ^ 1], ob, f1, tid);
-      if (k0 + 2 * GK < kend) {  // and stage s+2 starts its way from HBM / L2
-        const bool f2 = k0 + 3 * GK <= kend;
-        stage_load(ra, oa, k0 + 2 * GK, kend, f2, tid);
-        stage_load(rb, ob, k0 + 2 * GK, kend, f2, tid);
+      if (si + 2 < ns) {  // and stage s+2 starts its way from HBM / L2
+        const int k2 = kof(si + 2);
+        const bool f2 = k2 + GK <= kend;
+        stage_load(ra, oa, k2, kend, f2, tid);
+        stage_load(rb, ob, k2, kend, f2, tid);
       }
     }
 #pragma unroll
@@ -300,7 +322,7 @@ __global__ void splitk_reduce_kernel(GemmArgs g, int nsplit) {
 int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double *A, long a_is, long a_ks,
                 const double *B, long b_ks, long b_js, double beta, const double *E, long e_is, long e_js,
                 double *C, long c_is, long c_js, double *work, size_t work_elems, double gamma,
-                const double *E2) {
+                const double *E2, const GemmStageList *sl) {
   if (M <= 0 || N <= 0) return FLGP_OK;
   GemmArgs g;
   // orient so that the contiguous output dimension is the kernel's column dimension
@@ -317,11 +339,32 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
     g.E = E; g.e_is = e_is; g.e_js = e_js;
     g.C = C; g.c_is = c_is; g.c_js = c_js;
   }
+  g.klist = nullptr; g.nk = nullptr; g.klist_ld = 0; g.klist_on_rows = 0;
+  if (sl && sl->klist) {
+    // the list describes the k stages that matter for each tile of the operand the CALLER passed as A (sl->on_a)
+    // or as B; after the orientation swap above that operand may have become the other one
+    const bool swapped = (c_is == 1 && c_js != 1);
+    g.klist = sl->klist; g.nk = sl->nk; g.klist_ld = sl->ld;
+    g.klist_on_rows = (sl->on_a != swapped) ? 1 : 0;
+  }
   g.alpha = alpha; g.beta = beta; g.gamma = gamma;
   g.E2 = (gamma == 0.0) ? nullptr : E2;
   if (beta == 0.0) g.E = nullptr;
   const int ntiles = ceil_div(g.M, GB) * ceil_div(g.N, GB);
   int nsplit = 1;
+  if (g.klist) {
+    // block-sparse: the work is sl->total_stages tile-stages; aim at ~8 stages per block, at most 512 blocks
+    if (work) {
+      long want = sl->total_stages * (long)ceil_div(g.klist_on_rows ? g.N : g.M, GB) / 8;
+      if (want > 512) want = 512;
+      nsplit = (int)(want / ntiles);
+      if (nsplit > sl->max_stages / 4) nsplit = sl->max_stages / 4;
+      if (tuning("gemm_bs_nsplit", 0) > 0) nsplit = tuning("gemm_bs_nsplit", 0);
+      const size_t per = (size_t)g.M * g.N;
+      if ((size_t)nsplit * per > work_elems) nsplit = (int)(work_elems / per);
+      if (nsplit < 1) nsplit = 1;
+    }
+  } else
   if (work && ntiles < 256 && Kd >= 8 * GK) {
     nsplit = 512 / ntiles;
     const int maxk = Kd / (2 * GK);
@@ -332,11 +375,11 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
   }
   int klen = ceil_div(Kd > 0 ? Kd : 1, nsplit);
   klen = (klen + GK - 1) / GK * GK;
-  nsplit = ceil_div(Kd > 0 ? Kd : 1, klen);
+  if (!g.klist) nsplit = ceil_div(Kd > 0 ? Kd : 1, klen);
   g.ksplit_len = klen;
   g.part = work;
   // overlapping tiles write some elements twice: harmless unless the epilogue reads what it overwrites
-  g.shift_edges = (nsplit > 1 || ((const double *)g.C != g.E && (const double *)g.C != g.E2)) ? 1 : 0;
+  g.shift_edges = g.klist ? 0 : (nsplit > 1 || ((const double *)g.C != g.E && (const double *)g.C != g.E2)) ? 1 : 0;
   {
     ProfScope ps("gemm_f64_kernel", st, 2.0 * (double)M * (double)N * (double)Kd);
     // second record per shape class (large / medium / small) for the bench breakdown
@@ -381,7 +424,7 @@ extern "C" int flgp_dev_gemm(void *stream, int M, int N, int Kd, double alpha, c
                              size_t work_elems) {
   FLGP_REQUIRE(M >= 0 && N >= 0 && Kd >= 0 && A && B && C, "gemm: bad arguments");
   return gemm_launch((hipStream_t)stream, M, N, Kd, alpha, A, a_is, a_ks, B, b_ks, b_js, beta, E, e_is, e_js, C,
-                     c_is, c_js, d_work, work_elems, 0.0, nullptr);
+                     c_is, c_js, d_work, work_elems, 0.0, nullptr, nullptr);
 }
 
 extern "C" size_t flgp_dev_hk_workspace(int n0, int n1, int K, int gather0) {
