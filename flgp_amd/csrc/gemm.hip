@@ -381,9 +381,11 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
   // overlapping tiles write some elements twice: harmless unless the epilogue reads what it overwrites
   g.shift_edges = g.klist ? 0 : (nsplit > 1 || ((const double *)g.C != g.E && (const double *)g.C != g.E2)) ? 1 : 0;
   {
-    ProfScope ps("gemm_f64_kernel", st, 2.0 * (double)M * (double)N * (double)Kd);
+    // flops actually multiplied: with a stage list only the listed 16-deep stages of each 128-wide tile
+    const double fl = g.klist ? 2.0 * 16.0 * (double)GB * (double)sl->total_stages * (double)(g.klist_on_rows ? g.N : g.M)
+                              : 2.0 * (double)M * (double)N * (double)Kd;
+    ProfScope ps("gemm_f64_kernel", st, fl);
     // second record per shape class (large / medium / small) for the bench breakdown
-    const double fl = 2.0 * (double)M * (double)N * (double)Kd;
     ProfScope ps2(fl > 5e9 ? "gemm_large" : (fl > 2e8 ? "gemm_medium" : "gemm_small"), st, fl);
     hipLaunchKernelGGL(gemm_f64_kernel, dim3(ntiles, 1, nsplit), dim3(256), 0, st, g);
   }
