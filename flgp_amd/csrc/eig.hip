@@ -1202,7 +1202,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   w.gemm_ws_elems = dense ? 0 : eig_gemm_ws_elems(s, b);
   w.gemm_ws = dense ? nullptr : (double *)take(sizeof(double) * w.gemm_ws_elems);
   BlockSparseG bs;
-  if (!dense && s >= tuning("eig_bs_min_s", 3072) && tuning("eig_blocksparse", 1)) {
+  if (!dense && s >= std::max(1024, tuning("eig_bs_min_s", 3072)) && tuning("eig_blocksparse", 1)) {
     bs.ntile = (s + 127) / 128; bs.nstage = (s + 15) / 16;
     BsScratch sc;
     bs.Gp = (double *)take(sizeof(double) * (size_t)s * s);
