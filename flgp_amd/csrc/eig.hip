@@ -1635,9 +1635,9 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
         //  never converge, so their diagonal block of T stays dense -- measured: 2 sweeps put rmax
         //  back to 4e-2.  jacobi_refine diagonalises that block first.)
         if (it < 2)         // bounds and a rough Ritz basis are all that is needed yet: loose threshold, capped sweeps
-          FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps, tuning(it == 0 ? "eig_sweeps_it0" : "eig_sweeps_it1", 3), 1e10));
+          FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps, tuning(it == 0 ? "eig_sweeps_it0" : "eig_sweeps_it1", 2), 1e10));
         else if (rmax_prev > 5e-2)
-          FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps, tuning("eig_sweeps_it2", 3), 1e6));
+          FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps, tuning("eig_sweeps_it2", 2), 1e6));
         else
           FLGP_TRY(jacobi_refine(st, w.T, b, K, w, lam, &sweeps,
                                  std::max(1, (rmax_prev > 1e-4 * tuning("eig_refine3_above_e4", 2000) ? 3 : (rmax_prev > 1e-8 * tuning("eig_refine2_above_e8", 100) ? 2 : 1)) - tuning("eig_refine_minus", 0))));
