@@ -76,6 +76,17 @@ struct GemmStageList {
   bool on_a;
   long total_stages;    // sum of nk
   int max_stages;       // max of nk
+  // optional balanced partition: n_items work items {tile, first entry, end entry, z} (4 ints each) that cut every
+  // tile's list into pieces of similar length; nz[tile] pieces per tile, at most zmax
+  const int *wl;
+  int n_items;
+  const int *nz;
+  int zmax;
+  // optional: the listed blocks of the sparse operand copied out into one contiguous array, block e of tile t
+  // (e = off[t] + position in the tile's list) as 16 rows of 128 values (k-major, zero padded at the edges), so
+  // that a stage is one 16 KB read instead of 16 reads a matrix column apart
+  const double *packed;
+  const int *off;
 };
 
 // C(i,j) = alpha * sum_k A(i,k) B(k,j) + beta * E(i,j) + gamma * E2(i,j)   (gemm.hip)

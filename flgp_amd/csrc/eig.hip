@@ -689,7 +689,7 @@ static bool eig_use_dense(int s, int K) {
 
 static size_t eig_gemm_ws_elems(int s, int b) {
   // split-K partials: the s x b products use up to 8 splits, the b x b ones up to 128
-  size_t a = (size_t)8 * s * b, c = (size_t)128 * b * b;
+  size_t a = (size_t)16 * s * b, c = (size_t)128 * b * b;
   return a > c ? a : c;
 }
 
@@ -763,6 +763,20 @@ __global__ __launch_bounds__(128) void bs_count_kernel(const double *__restrict_
     __syncthreads();
   }
   if (threadIdx.x == 0) cnt[tile * nstage + stage] = red[0];
+}
+// block e = (tile t, stage g) of the list copied out: pack[e][kk][r] = Gp(t*128 + r, g*16 + kk), zero outside the matrix
+__global__ __launch_bounds__(256) void bs_pack_kernel(const double *__restrict__ Gp, int s, const int *__restrict__ klist,
+                                                      int kl_ld, const int *__restrict__ off, int ntile,
+                                                      double *__restrict__ pack) {
+  const int e = blockIdx.x;
+  int t = 0;
+  while (t + 1 < ntile && off[t + 1] <= e) ++t;      // few tiles: a linear search is fine
+  const int g = klist[(size_t)t * kl_ld + (e - off[t])];
+  for (int x = threadIdx.x; x < 16 * 128; x += 256) {
+    const int kk = x >> 7, r = x & 127;
+    const int i = t * 128 + r, k = g * 16 + kk;
+    pack[(size_t)e * 2048 + x] = (i < s && k < s) ? Gp[(size_t)k * s + i] : 0.0;
+  }
 }
 // the rest: non-zeros of row i that sit in blocks the GEMM skips.  One wave per row, column i of Gp read
 // contiguously (symmetry); count pass (fill == 0) and fill pass (entries in ascending k).
@@ -879,6 +893,10 @@ struct BlockSparseG {
   double *Gp = nullptr;
   int *perm = nullptr;
   int *klist = nullptr, *nk = nullptr;
+  int *wl = nullptr, *nz = nullptr;   // balanced work items for the tiled GEMM
+  double *pack = nullptr;             // the listed blocks, contiguous
+  int *off = nullptr;
+  int n_items = 0, zmax = 1;
   int ntile = 0, nstage = 0;
   long total = 0;
   int maxn = 0;
@@ -896,6 +914,8 @@ static size_t bs_workspace_bytes(int s, int b) {
   tot += align_up(sizeof(double) * (size_t)BS_SEEDS * BS_SEEDS);
   tot += 2 * align_up(sizeof(int) * (size_t)s);                                   // labels, perm
   tot += 2 * align_up(sizeof(int) * (size_t)ntile * nstage) + align_up(sizeof(int) * (size_t)ntile);   // counts, klist, nk
+  tot += align_up(sizeof(int) * (size_t)ntile * 16 * 4) + align_up(sizeof(int) * (size_t)ntile);          // work items, nz
+  tot += align_up(sizeof(int) * (size_t)(ntile + 1)) + align_up(sizeof(double) * 2048 * ((size_t)ntile * nstage / 2 + 1));   // packed blocks
   tot += align_up((size_t)ntile * nstage);                                        // dense flags
   tot += 2 * align_up(sizeof(int) * (size_t)(s + 1));                             // rptr, rcnt
   tot += align_up(sizeof(int) * (size_t)ntile * nstage * BS_DENSE) + align_up(sizeof(double) * (size_t)ntile * nstage * BS_DENSE);
@@ -991,10 +1011,43 @@ static int bs_setup(hipStream_t st, const double *dG, int ldg, int s, int b, dou
   if (tuning("eig_verbose", 0))
     fprintf(stderr, "[flgp eig] block-sparse G: %.1f %% of the 16x128 blocks kept for the tiled GEMM (max %d of %d stages per tile), %ld scattered non-zeros\n",
             100.0 * bs.dense_frac, maxn, nstage, rem_bound);
-  if (bs.dense_frac > 0.01 * tuning("eig_bs_max_pct", 50)) { bs.on = false; return FLGP_OK; }
+  if (bs.dense_frac > 0.01 * std::min(50, tuning("eig_bs_max_pct", 50))) { bs.on = false; return FLGP_OK; }
+  // pieces of similar length: a tile with a long list is cut into more of them (at most 16 partial planes)
+  std::vector<int> wl, nz(ntile, 1);
+  {
+    // one workgroup per CU (or a whole number of them): 276 blocks on 256 CUs take as long as 512 would
+    // (measured: the CUs that get two set the run time), so the piece length is the smallest that keeps
+    // pieces x column tiles within the target
+    const int n_other = (b + 127) / 128;
+    const int target = std::max(1, tuning("eig_bs_wgs", 256) / n_other);
+    int chunk = std::max(1, (int)((total + target - 1) / target));
+    auto count_items = [&](int ch) { long c = 0; for (int t = 0; t < ntile; ++t) c += std::max(1, (nk[t] + ch - 1) / ch); return c; };
+    while (count_items(chunk) > target && chunk < maxn) ++chunk;
+    chunk = std::max(chunk, (maxn + 15) / 16);
+    if (tuning("eig_bs_chunk", 0) > 0) chunk = std::max(tuning("eig_bs_chunk", 0), (maxn + 15) / 16);
+    int zmax = 1;
+    for (int t = 0; t < ntile; ++t) {
+      const int pieces = std::max(1, (nk[t] + chunk - 1) / chunk);
+      nz[t] = pieces; zmax = std::max(zmax, pieces);
+      for (int z = 0; z < pieces; ++z) {
+        wl.push_back(t); wl.push_back((int)((long)z * nk[t] / pieces)); wl.push_back((int)((long)(z + 1) * nk[t] / pieces));
+        wl.push_back(z);
+      }
+    }
+    bs.n_items = (int)wl.size() / 4; bs.zmax = zmax;
+  }
+  std::vector<int> off(ntile + 1, 0);
+  for (int t = 0; t < ntile; ++t) off[t + 1] = off[t] + nk[t];
+  FLGP_HIP(hipMemcpyAsync(bs.off, off.data(), sizeof(int) * (ntile + 1), hipMemcpyHostToDevice, st));
+  FLGP_HIP(hipMemcpyAsync(bs.wl, wl.data(), sizeof(int) * wl.size(), hipMemcpyHostToDevice, st));
+  FLGP_HIP(hipMemcpyAsync(bs.nz, nz.data(), sizeof(int) * ntile, hipMemcpyHostToDevice, st));
   FLGP_HIP(hipMemcpyAsync(bs.klist, klist.data(), sizeof(int) * klist.size(), hipMemcpyHostToDevice, st));
   FLGP_HIP(hipMemcpyAsync(bs.nk, nk.data(), sizeof(int) * ntile, hipMemcpyHostToDevice, st));
   FLGP_HIP(hipMemcpyAsync(sc.dense, dense.data(), dense.size(), hipMemcpyHostToDevice, st));
+  if (total > 0) {
+    hipLaunchKernelGGL(bs_pack_kernel, dim3((unsigned)total), dim3(256), 0, st, bs.Gp, s, bs.klist, nstage, bs.off, ntile, bs.pack);
+    FLGP_TRY(check_launch("bs_pack_kernel"));
+  }
   hipLaunchKernelGGL(bs_remainder_kernel, dim3(s), dim3(64), 0, st, bs.Gp, s, nstage, sc.dense, nullptr, sc.rcnt, nullptr,
                      nullptr, 0);
   FLGP_TRY(check_launch("bs_remainder_kernel"));
@@ -1014,7 +1067,6 @@ static int bs_setup(hipStream_t st, const double *dG, int ldg, int s, int b, dou
   FLGP_TRY(check_launch("bs_remainder_kernel"));
   FLGP_HIP(hipStreamSynchronize(st));
   bs.on = true;
-  (void)b;
   return FLGP_OK;
 }
 
@@ -1215,6 +1267,11 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     sc.cnt = (int *)take(sizeof(int) * (size_t)bs.ntile * bs.nstage);
     bs.klist = (int *)take(sizeof(int) * (size_t)bs.ntile * bs.nstage);
     bs.nk = (int *)take(sizeof(int) * (size_t)bs.ntile);
+    bs.wl = (int *)take(sizeof(int) * (size_t)bs.ntile * 16 * 4);
+    bs.nz = (int *)take(sizeof(int) * (size_t)bs.ntile);
+    bs.off = (int *)take(sizeof(int) * (size_t)(bs.ntile + 1));
+    // packed blocks: the block-sparse path is only taken below eig_bs_max_pct (50 %) of all blocks
+    bs.pack = (double *)take(sizeof(double) * 2048 * ((size_t)bs.ntile * bs.nstage / 2 + 1));
     sc.dense = (unsigned char *)take((size_t)bs.ntile * bs.nstage);
     bs.rptr = (int *)take(sizeof(int) * (size_t)(s + 1));
     sc.rcnt = (int *)take(sizeof(int) * (size_t)(s + 1));
@@ -1262,7 +1319,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   };
   auto gemmG_t = [&](const double *Xt, double alpha, double beta, const double *Et, double gamma, const double *E2t,
                      double *out_t) -> int {   // out_t = alpha X_t G' + beta E_t + gamma E2_t   (b x s)
-    GemmStageList sl{bs.klist, bs.nk, bs.nstage, false, bs.total, bs.maxn};
+    GemmStageList sl{bs.klist, bs.nk, bs.nstage, false, bs.total, bs.maxn, bs.wl, bs.n_items, bs.nz, bs.zmax, bs.pack, bs.off};
     FLGP_TRY(gemm_launch(st, b, s, s, alpha, Xt, 1, b, bs.Gp, s, 1, beta, Et, 1, b, out_t, 1, b, w.gemm_ws, w.gemm_ws_elems,
                          gamma, E2t, &sl));
     if (bs.rnnz > 0) {

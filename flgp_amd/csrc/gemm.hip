@@ -48,6 +48,10 @@ struct GemmArgs {
   // (k0 = stage * GK) at klist[tile * klist_ld ...]; the gridDim.z blocks of a tile share its list evenly.
   const int *klist, *nk;
   int klist_ld, klist_on_rows;
+  const int *wl, *nz;                 // balanced work items (see GemmStageList); gridDim.x = items x tiles of the other side
+  int n_other, zmax;
+  const double *packed;               // listed blocks of the row operand, contiguous (see GemmStageList)
+  const int *off;
 };
 
 // ---- operand staging: a 128(rows) x 16(k) tile goes global -> 8 registers per thread -> LDS [k][row].
@@ -195,8 +199,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   }
   // the shorter tile dimension runs fastest, so the blocks that are resident together on an XCD
   // share the long operand's panel through L2 and the short operand stays L2 resident
-  const int tm = (ntm <= ntn) ? bid % ntm : bid / ntn;
-  const int tn = (ntm <= ntn) ? bid / ntm : bid % ntn;
+  int tm = (ntm <= ntn) ? bid % ntm : bid / ntn;
+  int tn = (ntm <= ntn) ? bid / ntm : bid % ntn;
+  int zidx = blockIdx.z, wl_s0 = 0, wl_s1 = 0;
+  if (g.wl) {   // balanced block-sparse partition: this block's piece of one tile's stage list
+    const int item = blockIdx.x / g.n_other, other = blockIdx.x % g.n_other;
+    const int4 it = ((const int4 *)g.wl)[item];
+    if (g.klist_on_rows) { tm = it.x; tn = other; } else { tn = it.x; tm = other; }
+    wl_s0 = it.y; wl_s1 = it.z; zidx = it.w;
+  }
   int row0 = tm * GB, col0 = tn * GB;
   // An edge tile would stage its operands through the predicated path for all of its k range and, being
   // the slowest block, set the run time (measured: 286 us at 4992, 351 us at 5000).  Where it is safe the
@@ -210,12 +221,15 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   // the k stages of this block: a contiguous range (dense), or its share of the tile's stage list (block-sparse)
   int kbeg = 0, kend = g.Kd, ns;
   const int *kl = nullptr;
+  const double *pk = nullptr;   // this thread's pointer into the packed blocks of the row operand (stage 0 of its piece)
   if (g.klist) {
     const int t = g.klist_on_rows ? tm : tn;
     const int L = g.nk[t];
-    const int s0 = (int)((long)blockIdx.z * L / gridDim.z), s1 = (int)((long)(blockIdx.z + 1) * L / gridDim.z);
+    int s0 = (int)((long)blockIdx.z * L / gridDim.z), s1 = (int)((long)(blockIdx.z + 1) * L / gridDim.z);
+    if (g.wl) { s0 = wl_s0; s1 = wl_s1; }
     kl = g.klist + (size_t)t * g.klist_ld + s0;
     ns = s1 - s0;
+    if (g.packed) pk = g.packed + ((size_t)g.off[t] + s0) * (GK * GB) + 2 * (tid & 63) + (tid >> 6) * GB;
   } else {
     kbeg = blockIdx.z * g.ksplit_len;
     kend = kbeg + g.ksplit_len;
@@ -224,9 +238,24 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     if (ns < 0) ns = 0;
   }
   auto kof = [&](int si) { return kl ? kl[si] * GK : kbeg + si * GK; };
+  // operand A of stage si: from the packed blocks when there are any (always a full, in-range 16 x 128 block)
+  auto load_a = [&](double (&reg)[8], const Operand &o, int si, int k0, bool full) {
+    if (pk) {
+      const double *p = pk + (size_t)si * (GK * GB);
+#pragma unroll
+      for (int rep = 0; rep < 4; ++rep) {
+        const d2 v = *(const d2 *)(p + (4 * rep) * GB);
+        reg[2 * rep] = v[0];
+        reg[2 * rep + 1] = v[1];
+      }
+    } else {
+      stage_load(reg, o, k0, kend, full, tid);
+    }
+  };
 
-  const Operand oa = make_operand(g.A, g.a_is, g.a_ks, row0, g.M, tid);
+  Operand oa = make_operand(g.A, g.a_is, g.a_ks, row0, g.M, tid);
   const Operand ob = make_operand(g.B, g.b_js, g.b_ks, col0, g.N, tid);
+  if (pk) oa.mode = LOAD_RC;   // packed blocks use the row-contiguous thread mapping, edge tiles included
   d4 acc[4][4];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
@@ -237,14 +266,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   if (ns > 0) {
     const int k0 = kof(0);
     const bool f0 = k0 + GK <= kend;
-    stage_load(ra, oa, k0, kend, f0, tid);
+    load_a(ra, oa, 0, k0, f0);
     stage_load(rb, ob, k0, kend, f0, tid);
-    stage_store(ra, As2[0], oa, f0, tid);
+    stage_store(ra, As2[0], oa, f0 || pk, tid);
     stage_store(rb, Bs2[0], ob, f0, tid);
     if (ns > 1) {
       const int k1 = kof(1);
       const bool f1 = k1 + GK <= kend;
-      stage_load(ra, oa, k1, kend, f1, tid);
+      load_a(ra, oa, 1, k1, f1);
       stage_load(rb, ob, k1, kend, f1, tid);
     }
   }
@@ -256,12 +285,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     const double *As = As2[cur], *Bs = Bs2[cur];
     if (si + 1 < ns) {      // stage s+1 goes into the other buffer (last read before the previous barrier)
       const bool f1 = kof(si + 1) + GK <= kend;
-      stage_store(ra, As2[cur ^ 1], oa, f1, tid);
+      stage_store(ra, As2[cur ^ 1], oa, f1 || pk, tid);
       stage_store(rb, Bs2[cur ^ 1], ob, f1, tid);
       if (si + 2 < ns) {  // and stage s+2 starts its way from HBM / L2
         const int k2 = kof(si + 2);
         const bool f2 = k2 + GK <= kend;
-        stage_load(ra, oa, k2, kend, f2, tid);
+        load_a(ra, oa, si + 2, k2, f2);
         stage_load(rb, ob, k2, kend, f2, tid);
       }
     }
@@ -282,7 +311,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   }
 
   // epilogue: D(row = (lane>>4) + 4*reg, col = lane&15) of each 16x16 tile
-  const bool partial = gridDim.z > 1;
+  const bool partial = gridDim.z > 1 || (g.wl && g.zmax > 1);
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
@@ -294,7 +323,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         if (i < g.M && j < g.N) {
           const double v = acc[mi][ni][reg];
           if (partial) {
-            g.part[((size_t)blockIdx.z * g.M + i) * g.N + j] = v;
+            g.part[((size_t)zidx * g.M + i) * g.N + j] = v;
           } else {
             double o = g.alpha * v;
             if (g.E) o += g.beta * g.E[(size_t)i * g.e_is + (size_t)j * g.e_js];
@@ -312,6 +341,7 @@ __global__ void splitk_reduce_kernel(GemmArgs g, int nsplit) {
   if (idx >= (long)g.M * g.N) return;
   const int i = (int)(idx / g.N), j = (int)(idx % g.N);
   double v = 0.0;
+  if (g.wl) nsplit = g.nz[(g.klist_on_rows ? i : j) / GB];   // this tile's own number of pieces
   for (int z = 0; z < nsplit; ++z) v += g.part[((size_t)z * g.M + i) * g.N + j];  // fixed order
   double o = g.alpha * v;
   if (g.E) o += g.beta * g.E[(size_t)i * g.e_is + (size_t)j * g.e_js];
@@ -340,12 +370,15 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
     g.C = C; g.c_is = c_is; g.c_js = c_js;
   }
   g.klist = nullptr; g.nk = nullptr; g.klist_ld = 0; g.klist_on_rows = 0;
+  g.wl = nullptr; g.nz = nullptr; g.n_other = 1; g.zmax = 1;
+  g.packed = nullptr; g.off = nullptr;
   if (sl && sl->klist) {
     // the list describes the k stages that matter for each tile of the operand the CALLER passed as A (sl->on_a)
     // or as B; after the orientation swap above that operand may have become the other one
     const bool swapped = (c_is == 1 && c_js != 1);
     g.klist = sl->klist; g.nk = sl->nk; g.klist_ld = sl->ld;
     g.klist_on_rows = (sl->on_a != swapped) ? 1 : 0;
+    if (sl->packed && g.klist_on_rows && tuning("gemm_bs_packed", 1)) { g.packed = sl->packed; g.off = sl->off; }
   }
   g.alpha = alpha; g.beta = beta; g.gamma = gamma;
   g.E2 = (gamma == 0.0) ? nullptr : E2;
@@ -361,6 +394,11 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
       if (nsplit > sl->max_stages / 4) nsplit = sl->max_stages / 4;
       if (tuning("gemm_bs_nsplit", 0) > 0) nsplit = tuning("gemm_bs_nsplit", 0);
       const size_t per = (size_t)g.M * g.N;
+      if (sl->wl && (size_t)sl->zmax * per <= work_elems && tuning("gemm_bs_balanced", 1)) {
+        g.wl = sl->wl; g.nz = sl->nz; g.zmax = sl->zmax;
+        g.n_other = ceil_div(g.klist_on_rows ? g.N : g.M, GB);
+        nsplit = 1;
+      }
       if ((size_t)nsplit * per > work_elems) nsplit = (int)(work_elems / per);
       if (nsplit < 1) nsplit = 1;
     }
@@ -387,10 +425,11 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
     ProfScope ps("gemm_f64_kernel", st, fl);
     // second record per shape class (large / medium / small) for the bench breakdown
     ProfScope ps2(fl > 5e9 ? "gemm_large" : (fl > 2e8 ? "gemm_medium" : "gemm_small"), st, fl);
-    hipLaunchKernelGGL(gemm_f64_kernel, dim3(ntiles, 1, nsplit), dim3(256), 0, st, g);
+    if (g.wl) hipLaunchKernelGGL(gemm_f64_kernel, dim3(sl->n_items * g.n_other, 1, 1), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(gemm_f64_kernel, dim3(ntiles, 1, nsplit), dim3(256), 0, st, g);
   }
   FLGP_TRY(check_launch("gemm_f64_kernel"));
-  if (nsplit > 1) {
+  if (nsplit > 1 || (g.wl && g.zmax > 1)) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div((long)g.M * g.N, 256)), dim3(256), 0, st, g, nsplit);
     FLGP_TRY(check_launch("splitk_reduce_kernel"));
   }
