@@ -262,6 +262,43 @@ def test_eig_topk(stages, s, K):
         assert np.linalg.norm(Vr - V @ (V.T @ Vr)) < 1e-7
 
 
+def test_eig_blocksparse_matches_dense(stages):
+    """The Gram matrix of a neighbourhood graph is sparse; from s = 3072 on the solver permutes it and multiplies
+    only the populated 16 x 128 blocks (+ a CSR remainder).  That must not change the result beyond rounding:
+    same eigenpairs as the dense path and as LAPACK, for a manifold (swiss roll) and for clustered data, and for
+    a matrix without structure (where the solver must notice and stay dense)."""
+    from flgp_amd import _lib
+    L = _lib.lib()
+    K = 60
+    cases = []
+    for name, X in (("swiss", synth.swiss_roll(40000)[0]), ("mixture", synth.gaussian_mixture(40000, 8, components=6))):
+        n, s, r = X.shape[0], 3200, 6
+        sel = np.sort(synth.random_anchor_rows(n, s, seed=5))
+        U0 = np.asfortranarray(X[sel])
+        Z = api.cross_similarity_lae_cpp(X, U0, r, "normalized").toarray()
+        A = Z / np.sqrt(np.abs(Z.sum(0)) + 1e-9)
+        cases.append((name, A.T @ A))
+    rng = np.random.default_rng(8)
+    Qr, _ = np.linalg.qr(rng.normal(size=(3200, 3200)))
+    cases.append(("dense", (Qr * np.sort(rng.uniform(0, 1, 3200))[::-1]) @ Qr.T))
+    try:
+        for name, G in cases:
+            G = 0.5 * (G + G.T)
+            w = np.linalg.eigvalsh(G)[::-1][:K]
+            out = {}
+            for flag in (1, 0):
+                L.flgp_set_tuning(b"eig_blocksparse", flag)
+                eig, V, info = stages.eig_topk(torch.from_numpy(G).cuda(), K)
+                eig = eig.cpu().numpy(); V = to_np_cm(V)
+                np.testing.assert_allclose(eig, w, rtol=EIG_RTOL, atol=1e-13, err_msg=name)
+                np.testing.assert_allclose(V.T @ V, np.eye(K), atol=1e-10, err_msg=name)
+                assert np.abs(G @ V - V * eig).max() < 1e-9, name
+                out[flag] = (eig, V)
+            np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-10, atol=1e-13)
+    finally:
+        L.flgp_set_tuning(b"eig_blocksparse", 1)
+
+
 # ------------------------------------------------------------------------------ spectrum + heat kernel
 @pytest.mark.parametrize("n,d,s,r,K,root,gl", [
     (1500, 3, 120, 4, 20, True, "cluster-normalized"),
