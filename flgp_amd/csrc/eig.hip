@@ -575,22 +575,24 @@ __global__ void sym_scale_apply_kernel(double *__restrict__ S, int b, const doub
   S[e] = S[e] * dinv[i] * dinv[j];
 }
 
-// out[0] = |S - I|_F^2 (single block)
-__global__ __launch_bounds__(1024) void dist_to_identity_kernel(const double *__restrict__ S, int b, double *__restrict__ out) {
-  __shared__ double red[1024];
+// out[blk] = partial sums of |S - I|_F^2: DIST_BLOCKS blocks, fixed assignment and order (the host adds them)
+constexpr int DIST_BLOCKS = 32;
+__global__ __launch_bounds__(256) void dist_to_identity_kernel(const double *__restrict__ S, int b, double *__restrict__ out) {
+  __shared__ double red[256];
   double acc = 0.0;
-  for (long e = threadIdx.x; e < (long)b * b; e += 1024) {
+  const long tot = (long)b * b;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)DIST_BLOCKS * 256) {
     const int i = (int)(e % b), j = (int)(e / b);
     const double d = S[e] - (i == j ? 1.0 : 0.0);
     acc = __builtin_fma(d, d, acc);
   }
   red[threadIdx.x] = acc;
   __syncthreads();
-  for (int off = 512; off > 0; off >>= 1) {
+  for (int off = 128; off > 0; off >>= 1) {
     if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = red[0];
+  if (threadIdx.x == 0) out[blockIdx.x] = red[0];
 }
 
 __global__ void set_identity_kernel(double *__restrict__ M, int b) {
@@ -1369,11 +1371,14 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     return small_gemm(A1, B1, 1.0, 0.0, nullptr, out1);
   };
   auto dist_to_identity = [&](const double *M, double *out) -> int {
-    hipLaunchKernelGGL(dist_to_identity_kernel, dim3(1), dim3(1024), 0, st, M, b, w.res);
+    double part[DIST_BLOCKS];
+    hipLaunchKernelGGL(dist_to_identity_kernel, dim3(DIST_BLOCKS), dim3(256), 0, st, M, b, w.res);
     FLGP_TRY(check_launch("dist_to_identity_kernel"));
-    FLGP_HIP(hipMemcpyAsync(out, w.res, sizeof(double), hipMemcpyDeviceToHost, st));
+    FLGP_HIP(hipMemcpyAsync(part, w.res, sizeof(double) * DIST_BLOCKS, hipMemcpyDeviceToHost, st));
     FLGP_HIP(hipStreamSynchronize(st));
-    *out = std::sqrt(*out);
+    double sum = 0.0;
+    for (int q = 0; q < DIST_BLOCKS; ++q) sum += part[q];
+    *out = std::sqrt(sum);
     return FLGP_OK;
   };
   hipLaunchKernelGGL(set_identity_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, w.Id, b);
