@@ -405,7 +405,10 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
   } else
   if (work && ntiles < 256 && Kd >= 8 * GK) {
     nsplit = 512 / ntiles;
-    const int maxk = Kd / (2 * GK);
+    // at least gemm_min_stages (default 5) stages per block: with fewer, the partial planes (and the reduction that
+    // reads them back) cost more than the extra blocks gain -- the 256 x 256 x 5000 Gram products of the
+    // eigensolver spent 33 us in the reduction of 128 planes next to 26 us in the GEMM
+    const int maxk = Kd / (tuning("gemm_min_stages", 5) * GK);
     if (nsplit > maxk) nsplit = maxk;
     const size_t per = (size_t)g.M * g.N;
     if ((size_t)nsplit * per > work_elems) nsplit = (int)(work_elems / per);
