@@ -114,11 +114,18 @@ __global__ __launch_bounds__(64) void colsum_kernel(const double *__restrict__ v
   const int lane = threadIdx.x;
   const int p0 = colptr[j], p1 = colptr[j + 1];
   double acc = 0.0;
+  // the next 64 entries are gathered (two dependent loads) while the current 64 are added
+  double v = (p0 + lane < p1) ? val[pos[p0 + lane]] : 0.0;
   for (int pb = p0; pb < p1; pb += 64) {
-    const int p = pb + lane;
-    const double v = (p < p1) ? val[pos[p]] : 0.0;
+    const int pn = pb + 64 + lane;
+    const double vn = (pn < p1) ? val[pos[pn]] : 0.0;
     const int cnt = (p1 - pb < 64) ? p1 - pb : 64;
-    for (int l = 0; l < cnt; ++l) acc += __shfl(v, l, 64);
+    // lane l's value through v_readlane (l is wave-uniform): a ds_bpermute round trip per entry made this
+    // strictly sequential chain ~150 cycles a step
+    const int vlo = __double2loint(v), vhi = __double2hiint(v);
+    for (int l = 0; l < cnt; ++l)
+      acc += __hiloint2double(__builtin_amdgcn_readlane(vhi, l), __builtin_amdgcn_readlane(vlo, l));
+    v = vn;
   }
   if (lane == 0) colsum[j] = acc;
 }
