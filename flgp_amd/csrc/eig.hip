@@ -28,6 +28,22 @@
 
 namespace flgp {
 
+// Host wait for the stream.  The solver talks to the host ~50 times per solve (Jacobi convergence flags, Ritz
+// values, the Newton-Schulz checks); hipStreamSynchronize sleeps on an interrupt and costs ~35 us of idle GPU per
+// round trip, polling an event costs a few.
+static hipError_t stream_wait(hipStream_t st) {
+  if (tuning("eig_spin_wait", 1) == 0) return hipStreamSynchronize(st);
+  static thread_local hipEvent_t ev = nullptr;
+  if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ev = nullptr; return hipStreamSynchronize(st); }
+  hipError_t e = hipEventRecord(ev, st);
+  if (e != hipSuccess) return e;
+  for (;;) {
+    e = hipEventQuery(ev);
+    if (e != hipErrorNotReady) return e;
+  }
+}
+
+
 // ------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------
@@ -962,7 +978,7 @@ static int bs_setup(hipStream_t st, const double *dG, int ldg, int s, int b, dou
   std::vector<double> C((size_t)p * p);
   FLGP_HIP(hipMemcpyAsync(lab.data(), sc.lab, sizeof(int) * s, hipMemcpyDeviceToHost, st));
   FLGP_HIP(hipMemcpyAsync(C.data(), sc.C, sizeof(double) * p * p, hipMemcpyDeviceToHost, st));
-  FLGP_HIP(hipStreamSynchronize(st));
+  FLGP_HIP(stream_wait(st));
   // chain the clusters: start at the heaviest, always continue with the unused cluster most strongly tied to the last
   std::vector<int> order, rank(p + 1, p);
   std::vector<char> used(p, 0);
@@ -993,7 +1009,7 @@ static int bs_setup(hipStream_t st, const double *dG, int ldg, int s, int b, dou
   FLGP_TRY(check_launch("bs_count_kernel"));
   std::vector<int> cnt((size_t)ntile * nstage);
   FLGP_HIP(hipMemcpyAsync(cnt.data(), sc.cnt, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, st));
-  FLGP_HIP(hipStreamSynchronize(st));   // also keeps `perm` alive until its copy is done
+  FLGP_HIP(stream_wait(st));   // also keeps `perm` alive until its copy is done
   std::vector<int> klist((size_t)ntile * nstage), nk(ntile, 0);
   std::vector<unsigned char> dense((size_t)ntile * nstage, 0);
   long total = 0, nblocks = 0, rem_bound = 0;
@@ -1055,7 +1071,7 @@ static int bs_setup(hipStream_t st, const double *dG, int ldg, int s, int b, dou
   FLGP_TRY(check_launch("bs_remainder_kernel"));
   std::vector<int> rcnt(s), rptr(s + 1, 0);
   FLGP_HIP(hipMemcpyAsync(rcnt.data(), sc.rcnt, sizeof(int) * s, hipMemcpyDeviceToHost, st));
-  FLGP_HIP(hipStreamSynchronize(st));
+  FLGP_HIP(stream_wait(st));
   for (int i = 0; i < s; ++i) rptr[i + 1] = rptr[i] + rcnt[i];
   bs.rnnz = rptr[s];
   if (tuning("eig_verbose", 0)) {
@@ -1067,7 +1083,7 @@ static int bs_setup(hipStream_t st, const double *dG, int ldg, int s, int b, dou
   hipLaunchKernelGGL(bs_remainder_kernel, dim3(s), dim3(64), 0, st, bs.Gp, s, nstage, sc.dense, bs.rptr, sc.rcnt, bs.rcol,
                      bs.rval, 1);
   FLGP_TRY(check_launch("bs_remainder_kernel"));
-  FLGP_HIP(hipStreamSynchronize(st));
+  FLGP_HIP(stream_wait(st));
   bs.on = true;
   return FLGP_OK;
 }
@@ -1126,7 +1142,7 @@ static int jacobi_run(hipStream_t st, int b, EigWork &w, std::vector<double> &h_
     FLGP_TRY(check_launch("jac_round_kernel"));
     if (to_convergence && sw >= 2) {  // from the third sweep on, ask the device whether it is done
       FLGP_HIP(hipMemcpyAsync(h_flags, w.flags, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
-      FLGP_HIP(hipStreamSynchronize(st));
+      FLGP_HIP(stream_wait(st));
       if (h_flags[1]) break;
     }
   }
@@ -1135,7 +1151,7 @@ static int jacobi_run(hipStream_t st, int b, EigWork &w, std::vector<double> &h_
   h_lam.resize(b);
   FLGP_HIP(hipMemcpyAsync(h_lam.data(), w.lam, sizeof(double) * b, hipMemcpyDeviceToHost, st));
   FLGP_HIP(hipMemcpyAsync(h_flags, w.flags, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
-  FLGP_HIP(hipStreamSynchronize(st));
+  FLGP_HIP(stream_wait(st));
   if (sweeps_out) *sweeps_out = h_flags[2];
   if (strict && to_convergence && !h_flags[1]) {
     set_error("block Jacobi did not converge in %d sweeps (b=%d)", max_sweeps, b);
@@ -1212,7 +1228,7 @@ static int sorted_basis(hipStream_t st, const std::vector<double> &lam, const st
   hipLaunchKernelGGL(permute_scale_kernel, dim3(ceil_div((long)b * ncols, 256)), dim3(256), 0, st, w.JV, b, b,
                      w.perm, scale ? w.scale : nullptr, d_rowscale, ncols, w.W, b);
   FLGP_TRY(check_launch("permute_scale_kernel"));
-  FLGP_HIP(hipStreamSynchronize(st));  // order / scale are host vectors that may die after return
+  FLGP_HIP(stream_wait(st));  // order / scale are host vectors that may die after return
   return FLGP_OK;
 }
 
@@ -1297,7 +1313,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     FLGP_HIP(hipMemcpyAsync(d_values, vals.data(), sizeof(double) * K, hipMemcpyHostToDevice, st));
     FLGP_HIP(hipMemcpy2DAsync(dV, sizeof(double) * ldv, w.W, sizeof(double) * s, sizeof(double) * s, K,
                               hipMemcpyDeviceToDevice, st));
-    FLGP_HIP(hipStreamSynchronize(st));
+    FLGP_HIP(stream_wait(st));
     if (info) { info[0] = sweeps; info[2] = 1; }
     return FLGP_OK;
   }
@@ -1375,7 +1391,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     hipLaunchKernelGGL(dist_to_identity_kernel, dim3(DIST_BLOCKS), dim3(256), 0, st, M, b, w.res);
     FLGP_TRY(check_launch("dist_to_identity_kernel"));
     FLGP_HIP(hipMemcpyAsync(part, w.res, sizeof(double) * DIST_BLOCKS, hipMemcpyDeviceToHost, st));
-    FLGP_HIP(hipStreamSynchronize(st));
+    FLGP_HIP(stream_wait(st));
     double sum = 0.0;
     for (int q = 0; q < DIST_BLOCKS; ++q) sum += part[q];
     *out = std::sqrt(sum);
@@ -1603,7 +1619,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     hipLaunchKernelGGL(resid_kernel, dim3(K), dim3(256), 0, st, B, A, s, s, w.lam, w.res);
     FLGP_TRY(check_launch("resid_kernel"));
     FLGP_HIP(hipMemcpyAsync(res.data(), w.res, sizeof(double) * K, hipMemcpyDeviceToHost, st));
-    FLGP_HIP(hipStreamSynchronize(st));
+    FLGP_HIP(stream_wait(st));
     double rmax = 0.0;
     for (int j = 0; j < K; ++j) rmax = std::max(rmax, res[j]);
     *rmax_out = rmax;
@@ -1758,6 +1774,6 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     FLGP_HIP(hipMemcpy2DAsync(dV, sizeof(double) * ldv, result, sizeof(double) * s, sizeof(double) * s, K,
                               hipMemcpyDeviceToDevice, st));
   }
-  FLGP_HIP(hipStreamSynchronize(st));
+  FLGP_HIP(stream_wait(st));
   return FLGP_OK;
 }
