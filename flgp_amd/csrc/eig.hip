@@ -31,6 +31,21 @@ namespace flgp {
 // Host wait for the stream.  The solver talks to the host ~50 times per solve (Jacobi convergence flags, Ritz
 // values, the Newton-Schulz checks); hipStreamSynchronize sleeps on an interrupt and costs ~35 us of idle GPU per
 // round trip, polling an event costs a few.
+static thread_local hipEvent_t g_mark = nullptr;
+// stream_mark: remember this point of the stream; mark_wait: host waits until the stream has reached it
+static hipError_t stream_mark(hipStream_t st) {
+  if (!g_mark) {
+    const hipError_t e = hipEventCreateWithFlags(&g_mark, hipEventDisableTiming);
+    if (e != hipSuccess) { g_mark = nullptr; return e; }
+  }
+  return hipEventRecord(g_mark, st);
+}
+static hipError_t mark_wait() {
+  for (;;) {
+    const hipError_t e = hipEventQuery(g_mark);
+    if (e != hipErrorNotReady) return e;
+  }
+}
 static hipError_t stream_wait(hipStream_t st) {
   if (tuning("eig_spin_wait", 1) == 0) return hipStreamSynchronize(st);
   static thread_local hipEvent_t ev = nullptr;
@@ -1425,18 +1440,29 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
         std::swap(Zc, Zn);
       }
       {
-        double dm = 0.0;   // the last M must be the identity to rounding
-        FLGP_TRY(dist_to_identity(Mm, &dm));
+        // the last M must be the identity to rounding.  Its check is a host round trip: the rotation it would
+        // allow is enqueued behind the measurement first (a failed check just overwrites Qout later), so the
+        // GPU multiplies while the host reads the verdict
+        double part[DIST_BLOCKS];
+        hipLaunchKernelGGL(dist_to_identity_kernel, dim3(DIST_BLOCKS), dim3(256), 0, st, Mm, b, w.res);
+        FLGP_TRY(check_launch("dist_to_identity_kernel"));
+        FLGP_HIP(hipMemcpyAsync(part, w.res, sizeof(double) * DIST_BLOCKS, hipMemcpyDeviceToHost, st));
+        FLGP_HIP(stream_mark(st));
+        // Zc may live in JV or X2; the rotation needs diag(dinv) Z in W (Mm's buffer: read by the kernel above first)
+        hipLaunchKernelGGL(row_scale_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, Zc, b, w.dinv, w.W);
+        FLGP_TRY(check_launch("row_scale_kernel"));
+        FLGP_TRY(rotate(Yin, w.W, Qout));
+        FLGP_HIP(mark_wait());
+        double dm = 0.0;
+        for (int q = 0; q < DIST_BLOCKS; ++q) dm += part[q];
+        dm = std::sqrt(dm);
         ok = dm < 1e-13 * std::sqrt((double)b);
         if (tuning("eig_verbose", 0) > 1) fprintf(stderr, "[flgp orth] delta=%.3e kmax=%d dm=%.2e %s\n", delta, kmax, dm, ok ? "ok" : "FAILED");
       }
       if (ok) {
-        // Zc may live in JV or X2; the rotation needs diag(dinv) Z in W
-        hipLaunchKernelGGL(row_scale_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, Zc, b, w.dinv, w.W);
-        FLGP_TRY(check_launch("row_scale_kernel"));
         if (cond_out) *cond_out = (1.0 + delta) / std::max(1.0 - delta, 1e-3);
         ++ns_orths;
-        return rotate(Yin, w.W, Qout);
+        return FLGP_OK;
       }
       // did not contract: rebuild S and fall through to Jacobi
       FLGP_TRY(gram_small(Yin, Yin, w.T));
