@@ -1,5 +1,6 @@
 // Error reporting, device selection and tuning knobs of libflgp_hip.so.
 #include "common.h"
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -10,6 +11,7 @@ namespace flgp {
 static thread_local char g_err[512] = "";
 static std::mutex g_tune_mu;
 static std::map<std::string, int> g_tune;
+static std::atomic<int> g_tune_count{0};
 
 void set_error(const char *fmt, ...) {
   va_list ap;
@@ -19,6 +21,7 @@ void set_error(const char *fmt, ...) {
 }
 
 int tuning(const char *key, int dflt) {
+  if (g_tune_count.load(std::memory_order_acquire) == 0) return dflt;   // nothing set: no lock, no string
   std::lock_guard<std::mutex> lk(g_tune_mu);
   auto it = g_tune.find(key);
   return it == g_tune.end() ? dflt : it->second;
@@ -131,5 +134,6 @@ extern "C" int flgp_set_tuning(const char *key, int value) {
   auto it = g_tune.find(key);
   if (it != g_tune.end()) old = it->second;
   g_tune[key] = value;
+  g_tune_count.store((int)g_tune.size(), std::memory_order_release);
   return old;
 }
