@@ -1561,20 +1561,18 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   int since_rr = 0, it_meas = 0;
   double rate = 0.1, rmax_meas = 0.0;
 
-  // second stream: late Rayleigh-Ritz refinements (eight workgroups of Jacobi) run beside the filter's GEMMs
+  // second stream: late Rayleigh-Ritz refinements (eight workgroups of Jacobi) run beside the filter's GEMMs.
+  // Created once per host thread and kept (hipStreamCreate / Destroy cost the better part of a millisecond each).
   struct Side {
     hipStream_t st = nullptr;
     hipEvent_t ev = nullptr;
-    ~Side() {
-      if (ev) (void)hipEventDestroy(ev);
-      if (st) (void)hipStreamDestroy(st);
-    }
-  } side;
-  if (tuning("eig_overlap", 1)) {
+  };
+  static thread_local Side side;
+  if (tuning("eig_overlap", 1) && !side.st) {
     if (hipStreamCreateWithFlags(&side.st, hipStreamNonBlocking) != hipSuccess) side.st = nullptr;
     if (side.st && hipEventCreateWithFlags(&side.ev, hipEventDisableTiming) != hipSuccess) side.ev = nullptr;
   }
-  const bool can_overlap = side.st && side.ev;
+  const bool can_overlap = side.st && side.ev && tuning("eig_overlap", 1);
 
   // ---- Chebyshev filter on [0, cut], scaled to 1 at the top Ritz value
   struct FilterPlan { double c, e, sigma1; int m; };
