@@ -151,6 +151,18 @@ __device__ __forceinline__ void stage_load(double (&reg)[8], const Operand &o, i
       reg[2 * rep] = v[0];
       reg[2 * rep + 1] = v[1];
     }
+  } else if (o.mode == LOAD_RC) {
+    // the k tail of a row-contiguous operand keeps the wide mapping: k = k0 + (tid >> 6) + 4 rep is the same for
+    // all lanes of a wave, rows past kend read row kend - 1 (a valid address) and are zeroed
+    const int kq = k0 + (tid >> 6);
+#pragma unroll
+    for (int rep = 0; rep < 4; ++rep) {
+      const int k = kq + 4 * rep;
+      const int kc = (k < kend) ? k : kend - 1;
+      const d2 v = *(const d2 *)(o.fast + (size_t)(kc - (tid >> 6)) * o.ks);   // o.fast sits at k = tid >> 6
+      reg[2 * rep] = (k < kend) ? v[0] : 0.0;
+      reg[2 * rep + 1] = (k < kend) ? v[1] : 0.0;
+    }
   } else {
     tile_load_gen(reg, o.base, o.rs, o.ks, o.row0, o.nrows, k0, kend, o.row_contig, tid);
   }
@@ -158,7 +170,7 @@ __device__ __forceinline__ void stage_load(double (&reg)[8], const Operand &o, i
 
 __device__ __forceinline__ void stage_store(const double (&reg)[8], double *__restrict__ lds, const Operand &o, bool full,
                                             int tid) {
-  if (full && o.mode == LOAD_RC) {
+  if (o.mode == LOAD_RC) {      // (the tail stage of a row-contiguous operand uses this mapping too)
     double *q = lds + (tid >> 6) * GLD + 2 * (tid & 63);
 #pragma unroll
     for (int rep = 0; rep < 4; ++rep) {
