@@ -23,6 +23,7 @@
 // accumulated in V explicitly, so V stays orthogonal to rounding even for tiny eigenvalues.
 #include "common.h"
 #include <algorithm>
+#include <mutex>
 #include <cmath>
 #include <vector>
 
@@ -31,29 +32,67 @@ namespace flgp {
 // Host wait for the stream.  The solver talks to the host ~50 times per solve (Jacobi convergence flags, Ritz
 // values, the Newton-Schulz checks); hipStreamSynchronize sleeps on an interrupt and costs ~35 us of idle GPU per
 // round trip, polling an event costs a few.
-static thread_local hipEvent_t g_mark = nullptr;
+// The HIP objects a solve needs on the host side -- a second stream and three events -- come from a small pool
+// (creating and destroying a stream costs the better part of a millisecond; callers may solve from short-lived
+// threads, e.g. the bandwidth grid, so thread-local objects would pile up).  A solve borrows one set for its
+// duration; the pool only ever grows to the number of solves that were in flight at once.
+struct HostCtx {
+  int device = -1;
+  hipStream_t side = nullptr;
+  hipEvent_t side_ev = nullptr, mark_ev = nullptr, wait_ev = nullptr;
+};
+static std::mutex g_ctx_mu;
+static std::vector<HostCtx *> g_ctx_free;
+static thread_local HostCtx *g_ctx = nullptr;     // the set borrowed by the solve running on this thread
+
+struct HostCtxLease {
+  HostCtx *prev;
+  HostCtxLease() : prev(g_ctx) {
+    HostCtx *c = nullptr;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    {
+      std::lock_guard<std::mutex> lk(g_ctx_mu);
+      for (size_t q = 0; q < g_ctx_free.size(); ++q)
+        if (g_ctx_free[q]->device == dev) { c = g_ctx_free[q]; g_ctx_free.erase(g_ctx_free.begin() + q); break; }
+    }
+    if (!c) {
+      c = new HostCtx();
+      c->device = dev;
+      if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess) c->side = nullptr;
+      if (hipEventCreateWithFlags(&c->side_ev, hipEventDisableTiming) != hipSuccess) c->side_ev = nullptr;
+      if (hipEventCreateWithFlags(&c->mark_ev, hipEventDisableTiming) != hipSuccess) c->mark_ev = nullptr;
+      if (hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming) != hipSuccess) c->wait_ev = nullptr;
+    }
+    g_ctx = c;
+  }
+  ~HostCtxLease() {
+    {
+      std::lock_guard<std::mutex> lk(g_ctx_mu);
+      g_ctx_free.push_back(g_ctx);
+    }
+    g_ctx = prev;
+  }
+};
+
 // stream_mark: remember this point of the stream; mark_wait: host waits until the stream has reached it
 static hipError_t stream_mark(hipStream_t st) {
-  if (!g_mark) {
-    const hipError_t e = hipEventCreateWithFlags(&g_mark, hipEventDisableTiming);
-    if (e != hipSuccess) { g_mark = nullptr; return e; }
-  }
-  return hipEventRecord(g_mark, st);
+  if (!g_ctx || !g_ctx->mark_ev) return hipStreamSynchronize(st);
+  return hipEventRecord(g_ctx->mark_ev, st);
 }
 static hipError_t mark_wait() {
+  if (!g_ctx || !g_ctx->mark_ev) return hipSuccess;    // stream_mark synchronised instead
   for (;;) {
-    const hipError_t e = hipEventQuery(g_mark);
+    const hipError_t e = hipEventQuery(g_ctx->mark_ev);
     if (e != hipErrorNotReady) return e;
   }
 }
 static hipError_t stream_wait(hipStream_t st) {
-  if (tuning("eig_spin_wait", 1) == 0) return hipStreamSynchronize(st);
-  static thread_local hipEvent_t ev = nullptr;
-  if (!ev && hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { ev = nullptr; return hipStreamSynchronize(st); }
-  hipError_t e = hipEventRecord(ev, st);
+  if (!g_ctx || !g_ctx->wait_ev || tuning("eig_spin_wait", 1) == 0) return hipStreamSynchronize(st);
+  hipError_t e = hipEventRecord(g_ctx->wait_ev, st);
   if (e != hipSuccess) return e;
   for (;;) {
-    e = hipEventQuery(ev);
+    e = hipEventQuery(g_ctx->wait_ev);
     if (e != hipErrorNotReady) return e;
   }
 }
@@ -1261,6 +1300,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
                                  int *info) {
   hipStream_t st = (hipStream_t)stream;
   FLGP_REQUIRE(s >= 1 && ldg >= s && ldv >= s, "eig: bad shape");
+  HostCtxLease lease;   // second stream + events for this solve
   if (K < 0) K = s;
   FLGP_REQUIRE(K >= 1 && K <= s, "eig: need 1 <= K <= s (K=%d, s=%d)", K, s);
   FLGP_REQUIRE(work_bytes >= eig_workspace_bytes(s, K), "eig: workspace too small");
@@ -1561,17 +1601,11 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   int since_rr = 0, it_meas = 0;
   double rate = 0.1, rmax_meas = 0.0;
 
-  // second stream: late Rayleigh-Ritz refinements (eight workgroups of Jacobi) run beside the filter's GEMMs.
-  // Created once per host thread and kept (hipStreamCreate / Destroy cost the better part of a millisecond each).
+  // second stream: late Rayleigh-Ritz refinements (eight workgroups of Jacobi) run beside the filter's GEMMs
   struct Side {
-    hipStream_t st = nullptr;
-    hipEvent_t ev = nullptr;
-  };
-  static thread_local Side side;
-  if (tuning("eig_overlap", 1) && !side.st) {
-    if (hipStreamCreateWithFlags(&side.st, hipStreamNonBlocking) != hipSuccess) side.st = nullptr;
-    if (side.st && hipEventCreateWithFlags(&side.ev, hipEventDisableTiming) != hipSuccess) side.ev = nullptr;
-  }
+    hipStream_t st;
+    hipEvent_t ev;
+  } side{g_ctx ? g_ctx->side : nullptr, g_ctx ? g_ctx->side_ev : nullptr};
   const bool can_overlap = side.st && side.ev && tuning("eig_overlap", 1);
 
   // ---- Chebyshev filter on [0, cut], scaled to 1 at the top Ritz value
@@ -1687,7 +1721,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     //  Ritz step and its convergence test land on the iteration where the tolerance is expected to be met)
     const bool near_done = rmax_prev * rate <= 4.0 * tol;
     const bool early_skip = tuning("eig_skip_it1", 0) && it == 1;
-    const bool do_rr = !early_skip && !(rr_every > 1 && it >= 3 && rmax_prev < 1e-3 && since_rr + 1 < rr_every && !near_done);
+    const bool do_rr = !early_skip && !(rr_every > 1 && it >= 3 && rmax_prev < 1e-6 * tuning("eig_rr_skip_below_e6", 1000) && since_rr + 1 < rr_every && !near_done);
     // Late Rayleigh-Ritz steps only refine a nearly diagonal T: the filter does not wait for them.  It is
     // linear, p(G) (Q W) = (p(G) Q) W, so it runs on the block as it is, with the bounds of the previous
     // step (once the residuals are below 1e-3 they move in the third digit: measured, earlier steps lose

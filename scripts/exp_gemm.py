@@ -50,6 +50,8 @@ run("Q W   (s x b x b)", s, b, b, (1, s), (1, b), (1, s), 0)
 run("b x b x b", b, b, b, (1, b), (1, b), (1, b), 0)
 # heat kernel: H(a,b) = sum_k V0(a,k) Vw(b,k)
 run("HK n x m x K (col-major H)", n, m, K, (1, n), (m, 1), (1, n), 0, iters=5)
+run("HK with V0 stored k-contiguous (n x K row-major)", n, m, K, (K, 1), (m, 1), (1, n), 0, iters=5)
+run("HK with both operands k-contiguous", n, m, K, (K, 1), (1, K), (1, n), 0, iters=5)
 
 print("--- split-K sweep for G*Q")
 for ns in (2, 3, 4, 5, 6, 8, 10, 12):
