@@ -41,6 +41,13 @@ _SIGNATURES = {
     "flgp_hk_from_spectrum": (c_int, [P, P, c_int, c_int, c_double, P, c_int, P, c_int, P]),
     "flgp_heat_kernel_spectrum": (c_int, [P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_char_p, c_char_p,
                                           c_int, c_double, P, P]),
+    "flgp_eigenpair_from_host": (c_int, [P, P, c_int, c_int, P]),
+    "flgp_heat_kernel_spectrum_resident": (c_int, [P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_char_p, c_char_p,
+                                                   c_int, c_double, P]),
+    "flgp_eigenpair_dims": (c_int, [P, P, P]),
+    "flgp_eigenpair_to_host": (c_int, [P, P, P]),
+    "flgp_hk_from_eigenpair": (c_int, [P, c_int, c_double, P, c_int, P, c_int, P]),
+    "flgp_eigenpair_free": (None, [P]),
     "flgp_heat_kernel_covariance": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, c_double, c_int,
                                             c_char_p, c_char_p, c_int, c_double, P]),
     "flgp_se_spectrum_grid": (c_int, [P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, c_char_p, c_int, P, P, P, c_int]),

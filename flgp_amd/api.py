@@ -17,6 +17,8 @@ from __future__ import annotations
 
 from dataclasses import dataclass
 
+import ctypes
+
 import numpy as np
 
 from . import _lib
@@ -171,6 +173,63 @@ def HK_from_spectrum_cpp(eigenpair, K, t, idx0, idx1):
     check(_lib.lib().flgp_hk_from_spectrum(_ptr(vals), _ptr(vec), n, int(K), float(t), _ptr(idx0), idx0.size,
                                            _ptr(idx1), idx1.size, _ptr(H)))
     return H
+
+
+class ResidentEigenPair:
+    """An ``EigenPair`` that stays in HBM (include/flgp_hip.h, "device-resident EigenPair"): what the training
+    loop needs, since it calls ``HK_from_spectrum_cpp`` with the same pair and a new ``t`` on every objective
+    evaluation (reference src/train.cpp:17,30,363,471).  On the R side the handle is an external pointer."""
+
+    def __init__(self, handle):
+        self._h = handle
+        n = ctypes.c_int(); K = ctypes.c_int()
+        check(_lib.lib().flgp_eigenpair_dims(self._h, ctypes.byref(n), ctypes.byref(K)))
+        self.n, self.K = n.value, K.value
+
+    @classmethod
+    def from_host(cls, eigenpair):
+        vec = _f64(eigenpair.vectors, "vectors")
+        vals = np.ascontiguousarray(eigenpair.values, dtype=np.float64)
+        h = ctypes.c_void_p()
+        check(_lib.lib().flgp_eigenpair_from_host(_ptr(vals), _ptr(vec), vec.shape[0], vals.size, ctypes.byref(h)))
+        return cls(h)
+
+    def HK_from_spectrum_cpp(self, K, t, idx0, idx1):
+        idx0 = np.ascontiguousarray(idx0, dtype=np.int32); idx1 = np.ascontiguousarray(idx1, dtype=np.int32)
+        H = np.zeros((idx0.size, idx1.size), order="F")
+        check(_lib.lib().flgp_hk_from_eigenpair(self._h, int(K), float(t), _ptr(idx0), idx0.size, _ptr(idx1), idx1.size,
+                                                _ptr(H)))
+        return H
+
+    def to_host(self):
+        values = np.zeros(self.K); vectors = np.zeros((self.n, self.K), order="F")
+        check(_lib.lib().flgp_eigenpair_to_host(self._h, _ptr(values), _ptr(vectors)))
+        return EigenPair(values, vectors)
+
+    def free(self):
+        if self._h is not None:
+            _lib.lib().flgp_eigenpair_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def heat_kernel_spectrum_resident(X, X_new, s, r, K=-1, models=None, nstart=1, epsilon=0.1, U=None):
+    """``heat_kernel_spectrum_cpp`` whose EigenPair is not copied back (see :class:`ResidentEigenPair`)."""
+    models = dict(_DEFAULT_MODELS_CPP, **(models or {}))
+    X = _f64(X, "X"); X_new = _f64(X_new, "X_new")
+    X_all = np.asfortranarray(np.vstack([X, X_new]))
+    n, d = X_all.shape
+    U = _anchors(X_all, s, models, U, nstart)
+    h = ctypes.c_void_p()
+    check(_lib.lib().flgp_heat_kernel_spectrum_resident(_ptr(X_all), n, d, _ptr(U), s, U.shape[1], int(r), int(K),
+                                                        _b(models["kernel"]), _b(models["gl"]), int(bool(models["root"])),
+                                                        float(epsilon), ctypes.byref(h)))
+    return ResidentEigenPair(h)
 
 
 def subsample_cpp(X, s, method="kmeans", nstart=1, rng=None):

@@ -2,6 +2,7 @@
 // Each one stages R-owned host buffers into HBM, runs the device stages on one stream and
 // copies the result back; no state survives the call (as the reference: no handles/caches).
 #include "common.h"
+#include <memory>
 #include <cmath>
 #include <string>
 #include <thread>
@@ -334,6 +335,102 @@ extern "C" int flgp_hk_from_spectrum(const double *values, const double *vectors
   FLGP_HIP(hipStreamSynchronize(st.s));
   return FLGP_OK;
 }
+
+// ---- device-resident EigenPair
+struct flgp_eigenpair {
+  DevBuf values, vectors;   // K, n x K column-major
+  int n = 0, K = 0, device = 0;
+};
+
+static int hk_on_device(hipStream_t st, const double *d_values, const double *d_vectors, int n, int K, double t,
+                        const int *idx0, int n0, const int *idx1, int n1, double *H) {
+  for (int a = 0; a < n0; ++a) FLGP_REQUIRE(idx0[a] >= 0 && idx0[a] < n, "HK_from_spectrum: idx0[%d]=%d out of range", a, idx0[a]);
+  for (int b = 0; b < n1; ++b) FLGP_REQUIRE(idx1[b] >= 0 && idx1[b] < n, "HK_from_spectrum: idx1[%d]=%d out of range", b, idx1[b]);
+  DevBuf di0, di1, dH, work;
+  const bool r0 = is_range(idx0, n0), r1 = is_range(idx1, n1);
+  FLGP_TRY(dH.alloc(sizeof(double) * (size_t)n0 * n1));
+  FLGP_TRY(work.alloc(flgp_dev_hk_workspace(n0, n1, K, !r0)));
+  if (!r0) { FLGP_TRY(di0.alloc(sizeof(int) * n0)); FLGP_TRY(h2d(di0.p, idx0, sizeof(int) * n0, st)); }
+  if (!r1) { FLGP_TRY(di1.alloc(sizeof(int) * n1)); FLGP_TRY(h2d(di1.p, idx1, sizeof(int) * n1, st)); }
+  FLGP_TRY(flgp_dev_hk(st, d_values, K, t, d_vectors, n, r0 ? nullptr : di0.as<int>(), r0 ? idx0[0] : 0, n0, d_vectors, n,
+                       r1 ? nullptr : di1.as<int>(), r1 ? idx1[0] : 0, n1, dH.as<double>(), n0, work.as<double>()));
+  FLGP_TRY(d2h(H, dH.p, sizeof(double) * (size_t)n0 * n1, st));
+  FLGP_HIP(hipStreamSynchronize(st));
+  return FLGP_OK;
+}
+
+extern "C" int flgp_eigenpair_from_host(const double *values, const double *vectors, int n, int K, flgp_eigenpair **out) {
+  FLGP_REQUIRE(values && vectors && out, "eigenpair_from_host: null pointer");
+  FLGP_REQUIRE(n >= 1 && K >= 1, "eigenpair_from_host: bad shape");
+  *out = nullptr;
+  Stream st;
+  FLGP_TRY(st.create());
+  std::unique_ptr<flgp_eigenpair> ep(new flgp_eigenpair());
+  ep->n = n; ep->K = K;
+  FLGP_HIP(hipGetDevice(&ep->device));
+  FLGP_TRY(ep->values.alloc(sizeof(double) * (size_t)K));
+  FLGP_TRY(ep->vectors.alloc(sizeof(double) * (size_t)n * K));
+  FLGP_TRY(h2d(ep->values.p, values, sizeof(double) * (size_t)K, st.s));
+  FLGP_TRY(h2d(ep->vectors.p, vectors, sizeof(double) * (size_t)n * K, st.s));
+  FLGP_HIP(hipStreamSynchronize(st.s));
+  *out = ep.release();
+  return FLGP_OK;
+}
+
+extern "C" int flgp_heat_kernel_spectrum_resident(const double *X_all, int n, int d, const double *U, int s, int ucols,
+                                                  int r, int K, const char *kernel, const char *gl, int root,
+                                                  double epsilon, flgp_eigenpair **out) {
+  int se = 0;
+  FLGP_TRY(parse_kernel(kernel, &se));
+  const int glc = flgp_parse_gl(gl);
+  if (glc < 0) return glc;
+  FLGP_REQUIRE(out, "heat_kernel_spectrum_resident: null pointer");
+  *out = nullptr;
+  Stream st;
+  FLGP_TRY(st.create());
+  Sim S;
+  FLGP_TRY(upload_points(S, st.s, X_all, n, d, U, s, ucols, glc == FLGP_GL_CLUSTER_NORMALIZED));
+  FLGP_TRY(cross_similarity(S, st.s, r, se, glc, epsilon, ucols));
+  Spectrum P;
+  FLGP_TRY(spectrum(S, st.s, K, root, P, nullptr));
+  FLGP_HIP(hipStreamSynchronize(st.s));
+  std::unique_ptr<flgp_eigenpair> ep(new flgp_eigenpair());
+  ep->n = n; ep->K = P.K;
+  FLGP_HIP(hipGetDevice(&ep->device));
+  std::swap(ep->values.p, P.values.p);     // the buffers change owner: no copy
+  std::swap(ep->vectors.p, P.vectors.p);
+  *out = ep.release();
+  return FLGP_OK;
+}
+
+extern "C" int flgp_eigenpair_dims(const flgp_eigenpair *ep, int *n, int *K) {
+  FLGP_REQUIRE(ep, "eigenpair_dims: null handle");
+  if (n) *n = ep->n;
+  if (K) *K = ep->K;
+  return FLGP_OK;
+}
+
+extern "C" int flgp_eigenpair_to_host(const flgp_eigenpair *ep, double *values, double *vectors) {
+  FLGP_REQUIRE(ep, "eigenpair_to_host: null handle");
+  Stream st;
+  FLGP_TRY(st.create());
+  if (values) FLGP_TRY(d2h(values, ep->values.p, sizeof(double) * (size_t)ep->K, st.s));
+  if (vectors) FLGP_TRY(d2h(vectors, ep->vectors.p, sizeof(double) * (size_t)ep->n * ep->K, st.s));
+  FLGP_HIP(hipStreamSynchronize(st.s));
+  return FLGP_OK;
+}
+
+extern "C" int flgp_hk_from_eigenpair(const flgp_eigenpair *ep, int K, double t, const int *idx0, int n0, const int *idx1,
+                                      int n1, double *H) {
+  FLGP_REQUIRE(ep && idx0 && idx1 && H, "hk_from_eigenpair: null pointer");
+  FLGP_REQUIRE(K >= 1 && K <= ep->K && n0 >= 0 && n1 >= 0, "hk_from_eigenpair: need 1 <= K <= %d", ep->K);
+  if (n0 == 0 || n1 == 0) return FLGP_OK;
+  Stream st;
+  FLGP_TRY(st.create());
+  return hk_on_device(st.s, (const double *)ep->values.p, (const double *)ep->vectors.p, ep->n, K, t, idx0, n0, idx1, n1, H);
+}
+
+extern "C" void flgp_eigenpair_free(flgp_eigenpair *ep) { delete ep; }
 
 extern "C" int flgp_heat_kernel_spectrum(const double *X_all, int n, int d, const double *U, int s, int ucols,
                                          int r, int K, const char *kernel, const char *gl, int root,

@@ -378,6 +378,32 @@ def test_end_to_end_c1_like(oracle):
     np.testing.assert_allclose(em["eigenvalues"], 1 - vals, rtol=0, atol=1e-10)
 
 
+def test_resident_eigenpair_matches_host_path(oracle):
+    """the EigenPair kept in HBM gives, for every (t, idx0, idx1), the matrix the by-value entry point
+    gives -- same kernels, so bit for bit -- and the resident spectrum equals the copied-back one."""
+    X, U0, U = make_case(3000, 3, 200, 5, seed=21)
+    m = 400
+    models = dict(kernel="lae", gl="cluster-normalized", root=True)
+    ep = api.heat_kernel_spectrum_cpp(X[:m], X[m:], 200, 5, 40, models, U=U)
+    rp = api.heat_kernel_spectrum_resident(X[:m], X[m:], 200, 5, 40, models, U=U)
+    assert (rp.n, rp.K) == (3000, 40)
+    back = rp.to_host()
+    np.testing.assert_array_equal(back.values, ep.values)
+    np.testing.assert_array_equal(back.vectors, ep.vectors)
+    up = api.ResidentEigenPair.from_host(ep)
+    rng = np.random.default_rng(2)
+    for t, idx0, idx1, K in [(10.0, np.arange(m), np.arange(m), 40), (0.5, np.arange(3000), np.arange(m), 40),
+                             (3.0, rng.permutation(3000)[:257], rng.permutation(3000)[:33], 25)]:
+        ref = api.HK_from_spectrum_cpp(ep, K, t, idx0, idx1)
+        np.testing.assert_array_equal(rp.HK_from_spectrum_cpp(K, t, idx0, idx1), ref)
+        np.testing.assert_array_equal(up.HK_from_spectrum_cpp(K, t, idx0, idx1), ref)
+    with pytest.raises(api.FlgpError):
+        rp.HK_from_spectrum_cpp(41, 1.0, np.arange(3), np.arange(3))        # K beyond the stored pairs
+    with pytest.raises(api.FlgpError):
+        rp.HK_from_spectrum_cpp(10, 1.0, np.array([3000]), np.arange(3))    # row out of range
+    rp.free(); up.free()
+
+
 def test_se_bandwidth_grid(oracle):
     """the spectrum part of fit_se_*: one k-NN, ten bandwidths, spectra run concurrently."""
     import time
