@@ -47,6 +47,9 @@ _SIGNATURES = {
     "flgp_eigenpair_dims": (c_int, [P, P, P]),
     "flgp_eigenpair_to_host": (c_int, [P, P, P]),
     "flgp_hk_from_eigenpair": (c_int, [P, c_int, c_double, P, c_int, P, c_int, P]),
+    "flgp_eigenpair_vtv": (c_int, [P, c_int, P, c_int, P]),
+    "flgp_eigenpair_vty": (c_int, [P, c_int, P, c_int, P, c_int, P]),
+    "flgp_eigenpair_vc": (c_int, [P, c_int, P, c_int, P, c_int, P]),
     "flgp_eigenpair_free": (None, [P]),
     "flgp_heat_kernel_covariance": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, c_double, c_int,
                                             c_char_p, c_char_p, c_int, c_double, P]),
@@ -76,6 +79,7 @@ _SIGNATURES = {
                             P, c_int, P]),
     "flgp_dev_gemm": (c_int, [P, c_int, c_int, c_int, c_double, P, c_long, c_long, P, c_long, c_long,
                               c_double, P, c_long, c_long, P, c_long, c_long, P, c_size_t]),
+    "flgp_dev_gather_rows": (c_int, [P, P, c_int, P, c_int, c_int, P]),
     "flgp_dev_hk_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
 }
 

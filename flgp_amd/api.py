@@ -201,6 +201,29 @@ class ResidentEigenPair:
                                                 _ptr(H)))
         return H
 
+    def VtV(self, K, idx):
+        """V^T V for V = vectors[idx, 0:K] (src/train.cpp:400)"""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        out = np.zeros((K, K), order="F")
+        check(_lib.lib().flgp_eigenpair_vtv(self._h, int(K), _ptr(idx), idx.size, _ptr(out)))
+        return out
+
+    def VtY(self, K, idx, Y):
+        """V^T Y (src/train.cpp:404)"""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        Y = np.asfortranarray(np.asarray(Y, dtype=np.float64).reshape(idx.size, -1))
+        out = np.zeros((K, Y.shape[1]), order="F")
+        check(_lib.lib().flgp_eigenpair_vty(self._h, int(K), _ptr(idx), idx.size, _ptr(Y), Y.shape[1], _ptr(out)))
+        return out
+
+    def VC(self, K, idx, C):
+        """V C for a K x q matrix C (src/train.cpp:404, src/Predict.cpp:60-75)"""
+        idx = np.ascontiguousarray(idx, dtype=np.int32)
+        C = np.asfortranarray(np.asarray(C, dtype=np.float64).reshape(K, -1))
+        out = np.zeros((idx.size, C.shape[1]), order="F")
+        check(_lib.lib().flgp_eigenpair_vc(self._h, int(K), _ptr(idx), idx.size, _ptr(C), C.shape[1], _ptr(out)))
+        return out
+
     def to_host(self):
         values = np.zeros(self.K); vectors = np.zeros((self.n, self.K), order="F")
         check(_lib.lib().flgp_eigenpair_to_host(self._h, _ptr(values), _ptr(vectors)))

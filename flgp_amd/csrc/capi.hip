@@ -430,6 +430,86 @@ extern "C" int flgp_hk_from_eigenpair(const flgp_eigenpair *ep, int K, double t,
   return hk_on_device(st.s, (const double *)ep->values.p, (const double *)ep->vectors.p, ep->n, K, t, idx0, n0, idx1, n1, H);
 }
 
+// V = vectors[idx, 0:K] gathered into a dense m x K block on the device (a row range is used in place)
+struct GatheredV {
+  DevBuf buf, didx;
+  const double *V = nullptr;
+  long ld = 0;
+};
+static int gather_v(hipStream_t st, const flgp_eigenpair *ep, int K, const int *idx, int m, GatheredV &g) {
+  FLGP_REQUIRE(ep && idx, "eigenpair: null pointer");
+  FLGP_REQUIRE(K >= 1 && K <= ep->K && m >= 1, "eigenpair: need 1 <= K <= %d and m >= 1", ep->K);
+  for (int a = 0; a < m; ++a) FLGP_REQUIRE(idx[a] >= 0 && idx[a] < ep->n, "eigenpair: idx[%d]=%d out of range", a, idx[a]);
+  if (is_range(idx, m)) {
+    g.V = (const double *)ep->vectors.p + idx[0];
+    g.ld = ep->n;
+    return FLGP_OK;
+  }
+  FLGP_TRY(g.buf.alloc(sizeof(double) * (size_t)m * K));
+  FLGP_TRY(g.didx.alloc(sizeof(int) * (size_t)m));
+  FLGP_TRY(h2d(g.didx.p, idx, sizeof(int) * (size_t)m, st));
+  FLGP_TRY(flgp_dev_gather_rows(st, (const double *)ep->vectors.p, ep->n, g.didx.as<int>(), m, K, g.buf.as<double>()));
+  g.V = g.buf.as<double>();
+  g.ld = m;
+  return FLGP_OK;
+}
+
+extern "C" int flgp_eigenpair_vtv(const flgp_eigenpair *ep, int K, const int *idx, int m, double *VtV) {
+  FLGP_REQUIRE(VtV, "eigenpair_vtv: null pointer");
+  Stream st;
+  FLGP_TRY(st.create());
+  GatheredV g;
+  FLGP_TRY(gather_v(st.s, ep, K, idx, m, g));
+  DevBuf out, work;
+  const size_t we = (size_t)128 * K * K;
+  FLGP_TRY(out.alloc(sizeof(double) * (size_t)K * K));
+  FLGP_TRY(work.alloc(sizeof(double) * we));
+  // (K x m)(m x K): A(i,k) = V(k,i), B(k,j) = V(k,j)
+  FLGP_TRY(gemm_launch(st.s, K, K, m, 1.0, g.V, g.ld, 1, g.V, 1, g.ld, 0.0, nullptr, 0, 0, out.as<double>(), 1, K,
+                       work.as<double>(), we, 0.0, nullptr));
+  FLGP_TRY(d2h(VtV, out.p, sizeof(double) * (size_t)K * K, st.s));
+  FLGP_HIP(hipStreamSynchronize(st.s));
+  return FLGP_OK;
+}
+
+extern "C" int flgp_eigenpair_vty(const flgp_eigenpair *ep, int K, const int *idx, int m, const double *Y, int q,
+                                  double *VtY) {
+  FLGP_REQUIRE(Y && VtY && q >= 1, "eigenpair_vty: bad arguments");
+  Stream st;
+  FLGP_TRY(st.create());
+  GatheredV g;
+  FLGP_TRY(gather_v(st.s, ep, K, idx, m, g));
+  DevBuf dY, out, work;
+  const size_t we = (size_t)64 * K * q + 1024;
+  FLGP_TRY(dY.alloc(sizeof(double) * (size_t)m * q));
+  FLGP_TRY(out.alloc(sizeof(double) * (size_t)K * q));
+  FLGP_TRY(work.alloc(sizeof(double) * we));
+  FLGP_TRY(h2d(dY.p, Y, sizeof(double) * (size_t)m * q, st.s));
+  FLGP_TRY(gemm_launch(st.s, K, q, m, 1.0, g.V, g.ld, 1, dY.as<double>(), 1, m, 0.0, nullptr, 0, 0, out.as<double>(), 1, K,
+                       work.as<double>(), we, 0.0, nullptr));
+  FLGP_TRY(d2h(VtY, out.p, sizeof(double) * (size_t)K * q, st.s));
+  FLGP_HIP(hipStreamSynchronize(st.s));
+  return FLGP_OK;
+}
+
+extern "C" int flgp_eigenpair_vc(const flgp_eigenpair *ep, int K, const int *idx, int m, const double *C, int q,
+                                 double *VC) {
+  FLGP_REQUIRE(C && VC && q >= 1, "eigenpair_vc: bad arguments");
+  Stream st;
+  FLGP_TRY(st.create());
+  GatheredV g;
+  FLGP_TRY(gather_v(st.s, ep, K, idx, m, g));
+  DevBuf dC, out;
+  FLGP_TRY(dC.alloc(sizeof(double) * (size_t)K * q));
+  FLGP_TRY(out.alloc(sizeof(double) * (size_t)m * q));
+  FLGP_TRY(h2d(dC.p, C, sizeof(double) * (size_t)K * q, st.s));
+  FLGP_TRY(gemm_launch(st.s, m, q, K, 1.0, g.V, 1, g.ld, dC.as<double>(), 1, K, 0.0, nullptr, 0, 0, out.as<double>(), 1, m,
+                       nullptr, 0, 0.0, nullptr));
+  FLGP_TRY(d2h(VC, out.p, sizeof(double) * (size_t)m * q, st.s));
+  FLGP_HIP(hipStreamSynchronize(st.s));
+  return FLGP_OK;
+}
+
 extern "C" void flgp_eigenpair_free(flgp_eigenpair *ep) { delete ep; }
 
 extern "C" int flgp_heat_kernel_spectrum(const double *X_all, int n, int d, const double *U, int s, int ucols,

@@ -483,6 +483,15 @@ extern "C" int flgp_dev_gemm(void *stream, int M, int N, int Kd, double alpha, c
                      c_is, c_js, d_work, work_elems, 0.0, nullptr, nullptr);
 }
 
+extern "C" int flgp_dev_gather_rows(void *stream, const double *dV, int ld, const int *d_idx, int n0, int K,
+                                    double *d_out) {
+  FLGP_REQUIRE(dV && d_idx && d_out && n0 >= 0 && K >= 1, "gather_rows: bad arguments");
+  if (n0 == 0) return FLGP_OK;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div((long)n0 * K, 256)), dim3(256), 0, (hipStream_t)stream, dV, ld, d_idx,
+                     n0, K, d_out);
+  return check_launch("gather_rows_kernel");
+}
+
 extern "C" size_t flgp_dev_hk_workspace(int n0, int n1, int K, int gather0) {
   return sizeof(double) * ((size_t)n1 * K + (gather0 ? (size_t)n0 * K : 0)) + 256;
 }

@@ -401,6 +401,13 @@ def test_resident_eigenpair_matches_host_path(oracle):
         rp.HK_from_spectrum_cpp(41, 1.0, np.arange(3), np.arange(3))        # K beyond the stored pairs
     with pytest.raises(api.FlgpError):
         rp.HK_from_spectrum_cpp(10, 1.0, np.array([3000]), np.arange(3))    # row out of range
+    # the m > K consumers of V (src/train.cpp:393-433): V^T V, V^T Y, V C against numpy on the copied-back pair
+    for K, idx in [(40, np.arange(m)), (25, rng.permutation(3000)[:777])]:
+        V = ep.vectors[idx][:, :K]
+        Y = rng.normal(size=(idx.size, 3)); C = rng.normal(size=(K, 2))
+        np.testing.assert_allclose(rp.VtV(K, idx), V.T @ V, rtol=0, atol=1e-10 * idx.size)
+        np.testing.assert_allclose(rp.VtY(K, idx, Y), V.T @ Y, rtol=0, atol=1e-10 * idx.size)
+        np.testing.assert_allclose(rp.VC(K, idx, C), V @ C, rtol=0, atol=1e-11 * K)
     rp.free(); up.free()
 
 
