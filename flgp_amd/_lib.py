@@ -51,6 +51,8 @@ _SIGNATURES = {
     "flgp_eigenpair_vty": (c_int, [P, c_int, P, c_int, P, c_int, P]),
     "flgp_eigenpair_vc": (c_int, [P, c_int, P, c_int, P, c_int, P]),
     "flgp_eigenpair_free": (None, [P]),
+    "flgp_nystrom_eigenpair": (c_int, [P, c_int, c_int, P, c_int, c_double, c_int, P, P]),
+    "flgp_nystrom_eigenpair_resident": (c_int, [P, c_int, c_int, P, c_int, c_double, c_int, P]),
     "flgp_heat_kernel_covariance": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, c_double, c_int,
                                             c_char_p, c_char_p, c_int, c_double, P]),
     "flgp_se_spectrum_grid": (c_int, [P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, c_char_p, c_int, P, P, P, c_int]),
@@ -59,6 +61,7 @@ _SIGNATURES = {
     "flgp_dev_anchor_dpad": (c_int, [c_int]),
     "flgp_dev_anchor_rows": (c_int, [c_int]),
     "flgp_dev_anchor_prep": (c_int, [P, P, c_int, c_int, c_int, P, P]),
+    "flgp_dev_nystrom_eigenpair": (c_int, [P, P, c_int, c_int, c_int, P, c_int, c_int, c_double, c_int, P, P, c_int]),
     "flgp_dev_knn": (c_int, [P, P, c_int, c_int, c_int, P, P, c_int, c_int, P, P, c_int]),
     "flgp_dev_lae": (c_int, [P, P, c_int, c_int, c_int, P, c_int, c_int, P, c_int, P, P]),
     "flgp_dev_v_to_z": (c_int, [P, P, c_int, P]),

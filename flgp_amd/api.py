@@ -255,6 +255,23 @@ def heat_kernel_spectrum_resident(X, X_new, s, r, K=-1, models=None, nstart=1, e
     return ResidentEigenPair(h)
 
 
+def nystrom_eigenpair_cpp(X, U, a2, K, resident=False):
+    """The per-bandwidth block of the ``fit_nystrom_*`` drivers (reference src/Fit.cpp:244-289): Gaussian similarity
+    of the anchors with the double normalisation, ``eigs_sym(W_UU, K)``, and the Nystrom extension to the rows of
+    ``X``.  ``U`` is s x d (cluster-size column already dropped, as ``.leftCols(d)`` does at :242)."""
+    X = _f64(X, "X"); U = _f64(U, "U")
+    if X.shape[1] != U.shape[1]:
+        raise ValueError("X and U must have the same number of columns")
+    n, d = X.shape; s = U.shape[0]
+    if resident:
+        h = ctypes.c_void_p()
+        check(_lib.lib().flgp_nystrom_eigenpair_resident(_ptr(X), n, d, _ptr(U), s, float(a2), int(K), ctypes.byref(h)))
+        return ResidentEigenPair(h)
+    values = np.zeros(int(K)); vectors = np.zeros((n, int(K)), order="F")
+    check(_lib.lib().flgp_nystrom_eigenpair(_ptr(X), n, d, _ptr(U), s, float(a2), int(K), _ptr(values), _ptr(vectors)))
+    return EigenPair(values, vectors)
+
+
 def subsample_cpp(X, s, method="kmeans", nstart=1, rng=None):
     """subsample_cpp (src/Utils.cpp:32-68).  Only ``method="random"`` exists outside R (rows drawn
     without replacement by a numpy Generator instead of R's ``sample``); k-means anchors come

@@ -403,6 +403,53 @@ extern "C" int flgp_heat_kernel_spectrum_resident(const double *X_all, int n, in
   return FLGP_OK;
 }
 
+// ---- Nystrom-extension spectrum (reference src/Fit.cpp:244-289)
+extern "C" int flgp_dev_nystrom_eigenpair(void *stream, const double *dX, int n, int ldx, int d, const double *dU, int s,
+                                          int ldu, double a2, int K, double *d_values, double *d_vectors, int ldv);
+
+static int nystrom_on_device(hipStream_t st, const double *X, int n, int d, const double *U, int s, double a2, int K,
+                             DevBuf &dval, DevBuf &dvec) {
+  FLGP_REQUIRE(X && U, "nystrom_eigenpair: null pointer");
+  FLGP_REQUIRE(n >= 1 && d >= 1 && s >= 2 && K >= 1 && K <= s, "nystrom_eigenpair: bad shape (n=%d d=%d s=%d K=%d)", n, d, s, K);
+  DevBuf dX, dU;
+  FLGP_TRY(dX.alloc(sizeof(double) * (size_t)n * d));
+  FLGP_TRY(dU.alloc(sizeof(double) * (size_t)s * d));
+  FLGP_TRY(dval.alloc(sizeof(double) * (size_t)K));
+  FLGP_TRY(dvec.alloc(sizeof(double) * (size_t)n * K));
+  FLGP_TRY(h2d(dX.p, X, sizeof(double) * (size_t)n * d, st));
+  FLGP_TRY(h2d(dU.p, U, sizeof(double) * (size_t)s * d, st));
+  return flgp_dev_nystrom_eigenpair(st, dX.as<double>(), n, n, d, dU.as<double>(), s, s, a2, K, dval.as<double>(),
+                                    dvec.as<double>(), n);
+}
+
+extern "C" int flgp_nystrom_eigenpair(const double *X, int n, int d, const double *U, int s, double a2, int K,
+                                      double *values, double *vectors) {
+  FLGP_REQUIRE(values && vectors, "nystrom_eigenpair: null pointer");
+  Stream st;
+  FLGP_TRY(st.create());
+  DevBuf dval, dvec;
+  FLGP_TRY(nystrom_on_device(st.s, X, n, d, U, s, a2, K, dval, dvec));
+  FLGP_TRY(d2h(values, dval.p, sizeof(double) * (size_t)K, st.s));
+  FLGP_TRY(d2h(vectors, dvec.p, sizeof(double) * (size_t)n * K, st.s));
+  FLGP_HIP(hipStreamSynchronize(st.s));
+  return FLGP_OK;
+}
+
+extern "C" int flgp_nystrom_eigenpair_resident(const double *X, int n, int d, const double *U, int s, double a2, int K,
+                                               flgp_eigenpair **out) {
+  FLGP_REQUIRE(out, "nystrom_eigenpair_resident: null pointer");
+  *out = nullptr;
+  Stream st;
+  FLGP_TRY(st.create());
+  std::unique_ptr<flgp_eigenpair> ep(new flgp_eigenpair());
+  FLGP_TRY(nystrom_on_device(st.s, X, n, d, U, s, a2, K, ep->values, ep->vectors));
+  FLGP_HIP(hipStreamSynchronize(st.s));
+  ep->n = n; ep->K = K;
+  FLGP_HIP(hipGetDevice(&ep->device));
+  *out = ep.release();
+  return FLGP_OK;
+}
+
 extern "C" int flgp_eigenpair_dims(const flgp_eigenpair *ep, int *n, int *K) {
   FLGP_REQUIRE(ep, "eigenpair_dims: null handle");
   if (n) *n = ep->n;

@@ -426,3 +426,33 @@ def np_spectrum_dense(Z, K, root=False):
 def np_hk(values, vectors, K, t, idx0, idx1):
     w = np.exp(-t * (1.0 - np.asarray(values)[:K]))
     return (vectors[idx0, :K] * w[None, :]) @ vectors[idx1, :K].T
+
+
+def np_nystrom_eigenpair(X_all, U, a2, K):
+    """The Nystrom-extension spectrum the ``fit_nystrom_*`` drivers build per bandwidth ``a2`` (reference
+    src/Fit.cpp:244-286; identical in :399-441, :918-960, :1063-1105 ...), restated line by line in numpy.
+    ``eigs_sym`` (RSpectra, largest magnitude) is replaced by LAPACK ``eigh`` + the K largest eigenvalues: W_UU is a
+    congruence of the positive-definite Gaussian kernel matrix, so largest magnitude = largest.
+    Returns (values (K,), vectors (n, K)); eigenvector signs are arbitrary, as in the reference."""
+    X_all = np.asarray(X_all, dtype=np.float64); U = np.asarray(U, dtype=np.float64)
+    s = U.shape[0]
+    uu = (U * U).sum(1)
+    D_UU = (-2.0 * U @ U.T + uu[:, None]) + uu[None, :]                       # :244
+    D_XU = (-2.0 * X_all @ U.T + (X_all * X_all).sum(1)[:, None]) + uu[None, :]   # :245
+    mean = D_UU.sum() / (s * s)                                             # :248
+    Z_UU = np.exp(-D_UU / (a2 * mean))                                      # :266
+    rs_UU = Z_UU.sum(1) + 1e-9                                              # :267
+    A_UU = (Z_UU / rs_UU[:, None]) / rs_UU[None, :]                         # :268
+    sd = 1.0 / np.sqrt(A_UU.sum(1) + 1e-9)                                  # :269
+    W_UU = (A_UU * sd[:, None]) * sd[None, :]                               # :270
+    w, V = np.linalg.eigh(0.5 * (W_UU + W_UU.T))
+    order = np.argsort(-w)[:K]
+    values = w[order]; V = V[:, order]                                      # :273-276
+    V = sd[:, None] * V                                                     # :278
+    V = np.sqrt(s) * V / (np.linalg.norm(V, axis=0) + 1e-9)[None, :]        # :279-280
+    Z_XU = np.exp(-D_XU / (a2 * mean))                                      # :283
+    rs_XU = Z_XU.sum(1) + 1e-9                                              # :284
+    A_XU = (Z_XU / rs_XU[:, None]) / rs_UU[None, :]                         # :285
+    W_XU = A_XU / (A_XU.sum(1) + 1e-9)[:, None]                             # :286-287
+    vectors = (W_XU @ V) / (np.abs(values) + 1e-9)[None, :]                 # :289
+    return values, vectors

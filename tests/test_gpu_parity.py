@@ -411,6 +411,52 @@ def test_resident_eigenpair_matches_host_path(oracle):
     rp.free(); up.free()
 
 
+@pytest.mark.parametrize("n,d,s,a2,K,seed", [(3000, 3, 300, 1.0, 30, 0), (5000, 7, 500, 0.5, 60, 1),
+                                              (2000, 16, 257, 10.0, 20, 2), (700, 2, 64, 0.1, 64 // 4, 3)])
+def test_nystrom_eigenpair(oracle, n, d, s, a2, K, seed):
+    """the Nystrom-extension spectrum of fit_nystrom_* (reference src/Fit.cpp:244-289) against the numpy
+    restatement.  fp64 tolerance, not bit-exact: the reference's distances come from an Eigen GEMM and its eigenpairs
+    from ARPACK.  An eigenvector is determined up to sign and to 1/gap, so the bound is on error x relative gap."""
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(n, d)); U = X[rng.permutation(n)[:s]] + 0.01 * rng.normal(size=(s, d))
+    vals, vecs = oracle.np_nystrom_eigenpair(X, U, a2, K)
+    ep = api.nystrom_eigenpair_cpp(X, U, a2, K)
+    np.testing.assert_allclose(ep.values, vals, rtol=1e-10, atol=0)
+    sign = np.sign(np.sum(ep.vectors * vecs, axis=0))
+    err = np.max(np.abs(ep.vectors * sign - vecs), axis=0) / np.max(np.abs(vecs), axis=0)
+    gap = np.minimum(np.abs(np.diff(vals, prepend=np.inf)), np.abs(np.diff(vals, append=-np.inf))) / vals[0]
+    assert np.max(err[:-1] * gap[:-1]) < 1e-10, (err, gap)      # the last pair's lower neighbour is not computed
+    assert err[0] < 1e-12                                       # the trivial pair (value 1) is well separated
+    # the resident variant holds the same numbers and feeds HK_from_spectrum_cpp
+    rp = api.nystrom_eigenpair_cpp(X, U, a2, K, resident=True)
+    assert (rp.n, rp.K) == (n, K)
+    back = rp.to_host()
+    np.testing.assert_array_equal(back.values, ep.values)
+    np.testing.assert_array_equal(back.vectors, ep.vectors)
+    idx = np.arange(min(n, 200))
+    H = rp.HK_from_spectrum_cpp(K, 1.0, idx, idx)
+    np.testing.assert_array_equal(H, api.HK_from_spectrum_cpp(ep, K, 1.0, idx, idx))
+    rp.free()
+
+
+def test_nystrom_eigenpair_blocks_and_errors(oracle):
+    """more rows than one row block of the extension holds; argument checks"""
+    rng = np.random.default_rng(5)
+    n, d, s, K = 70000, 4, 2100, 12            # row block = one round of the GEMM grid = 65536 rows: two blocks
+    X = rng.normal(size=(n, d)); U = X[rng.permutation(n)[:s]]
+    vals, vecs = oracle.np_nystrom_eigenpair(X, U, 1.0, K)
+    ep = api.nystrom_eigenpair_cpp(X, U, 1.0, K)
+    np.testing.assert_allclose(ep.values, vals, rtol=1e-10, atol=0)
+    sign = np.sign(np.sum(ep.vectors * vecs, axis=0))
+    np.testing.assert_allclose((ep.vectors * sign)[:, :4], vecs[:, :4], rtol=0, atol=1e-9 * np.max(np.abs(vecs[:, :4])))
+    with pytest.raises(api.FlgpError):
+        api.nystrom_eigenpair_cpp(X[:100], U[:10], 1.0, 11)       # K > s
+    with pytest.raises(api.FlgpError):
+        api.nystrom_eigenpair_cpp(X[:100], U[:10], 0.0, 3)        # a2 must be positive
+    with pytest.raises(api.FlgpError):
+        api.nystrom_eigenpair_cpp(X[:100], np.tile(U[:1], (10, 1)), 1.0, 3)   # coincident anchors: mean distance 0
+
+
 def test_se_bandwidth_grid(oracle):
     """the spectrum part of fit_se_*: one k-NN, ten bandwidths, spectra run concurrently."""
     import time

@@ -135,6 +135,24 @@ def test_spectrum_routes_agree(oracle):
         assert np.abs(H - Href).max() <= 1e-9 * np.abs(Href).max()
 
 
+def test_nystrom_restatement_properties(oracle):
+    """np_nystrom_eigenpair (reference src/Fit.cpp:244-289): the leading pair is the trivial one (value 1, constant
+    vector), and extending to the anchors themselves returns the anchor eigenvectors -- D^-1 A and D^-1/2 A D^-1/2
+    share eigenvalues, and W_XU V / lambda = V for X = U."""
+    rng = np.random.default_rng(0)
+    s, d, K = 120, 3, 10
+    U = rng.normal(size=(s, d)); X = np.vstack([U, rng.normal(size=(300, d))])
+    vals, vecs = oracle.np_nystrom_eigenpair(X, U, 1.0, K)
+    assert vecs.shape == (420, K) and np.all(np.diff(vals) <= 0)
+    assert abs(vals[0] - 1.0) < 1e-6
+    assert np.ptp(vecs[:, 0]) < 1e-5 * abs(vecs[0, 0])                 # constant vector, also off the anchors
+    np.testing.assert_allclose(np.linalg.norm(vecs[:s], axis=0), np.sqrt(s), rtol=1e-5)     # sqrt(s) column norm (:280)
+    D = ((U[:, None, :] - U[None, :, :]) ** 2).sum(-1)
+    Z = np.exp(-D / (1.0 * D.sum() / s ** 2)); rs = Z.sum(1); A = Z / rs[:, None] / rs[None, :]
+    P = A / A.sum(1)[:, None]                                           # random-walk matrix of the anchor graph
+    np.testing.assert_allclose(P @ vecs[:s], vecs[:s] * vals, atol=1e-6)
+
+
 def test_hk_c_vs_numpy(oracle):
     rng = np.random.default_rng(5)
     n, K = 37, 6
