@@ -50,6 +50,37 @@ __global__ __launch_bounds__(256) void nys_sim_kernel(const double *__restrict__
   }
 }
 
+// d > 32: the dot products come from the MFMA GEMM (a k-ascending FMA chain from 0, the same bits as the chain
+// above); the 64 anchor coordinates of the scalar-operand kernel no longer fit the SGPR file and its loads stall.
+__global__ void nys_sqnorm_kernel(const double *__restrict__ X, int nb, int ldx, int d, double *__restrict__ xx) {
+  const int x = blockIdx.x * blockDim.x + threadIdx.x;
+  if (x >= nb) return;
+  double a = X[x] * X[x];
+  for (int k = 1; k < d; ++k) a = __builtin_fma(X[(size_t)k * ldx + x], X[(size_t)k * ldx + x], a);
+  xx[x] = a;
+}
+// in place on the dot products: Z(x, j) = exp(-(fma(-2, dot, xx) + uu_j) inv_c), with the two partial row sums
+__global__ __launch_bounds__(256) void nys_exp_rows_kernel(double *__restrict__ Z, int nb, int s, const double *__restrict__ xx,
+                                                           const double *__restrict__ uu, double inv_c,
+                                                           const double *__restrict__ w, double *__restrict__ part1,
+                                                           double *__restrict__ part2) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= nb) return;
+  const double xn = xx[x];
+  const int j0 = blockIdx.y * 64, j1 = (j0 + 64 < s) ? j0 + 64 : s;
+  double a1 = 0.0, a2 = 0.0;
+#pragma unroll 8
+  for (int j = j0; j < j1; ++j) {
+    const double D = __builtin_fma(-2.0, Z[(size_t)j * nb + x], xn) + uu[j];
+    const double v = exp(-D * inv_c);
+    Z[(size_t)j * nb + x] = v;
+    a1 += v;
+    a2 += v * w[j];
+  }
+  part1[(size_t)blockIdx.y * nb + x] = a1;
+  part2[(size_t)blockIdx.y * nb + x] = a2;
+}
+
 // r1[x] = sum over chunks (ascending) of part1[chunk][x] (+ add1); same for r2
 __global__ void nys_reduce_kernel(const double *__restrict__ part1, const double *__restrict__ part2, int nchunk, int nb,
                                   double add1, double *__restrict__ r1, double *__restrict__ r2) {
@@ -223,12 +254,24 @@ extern "C" int flgp_dev_nystrom_eigenpair(void *stream, const double *dX, int n,
                      nrm.as<double>(), rsu.as<double>(), d_values, std::sqrt((double)s));
   FLGP_TRY(check_launch("nystrom V_UU"));
   // ---- extension, row block by row block (:283-289)
+  // without a workspace gemm_launch cannot split k, so every dot product is one whole chain
+  const bool via_gemm = tuning("nystrom_dot_gemm", -1) == 1 || (tuning("nystrom_dot_gemm", -1) < 0 && dpad > 32);
   const size_t gws_elems = (size_t)8 * NB * K;
   FLGP_TRY(gws.alloc(sizeof(double) * gws_elems));
   for (int x0 = 0; x0 < n; x0 += NB) {
     const int nb = (n - x0 < NB) ? n - x0 : NB;
-    FLGP_TRY((launch_sim<1>(st, dpad, dX + x0, nb, ldx, d, Ut.as<double>(), uu.as<double>(), s, inv_c, rsu.as<double>(),
-                            Zb.as<double>(), nb, p1.as<double>(), p2.as<double>())));
+    if (via_gemm) {
+      hipLaunchKernelGGL(nys_sqnorm_kernel, dim3(ceil_div(nb, 256)), dim3(256), 0, st, dX + x0, nb, ldx, d, fac.as<double>());
+      FLGP_TRY(check_launch("nys_sqnorm_kernel"));
+      FLGP_TRY(gemm_launch(st, nb, s, d, 1.0, dX + x0, 1, ldx, dU, ldu, 1, 0.0, nullptr, 0, 0, Zb.as<double>(), 1, nb,
+                           nullptr, 0, 0.0, nullptr));
+      hipLaunchKernelGGL(nys_exp_rows_kernel, dim3(ceil_div(nb, 256), nchunk), dim3(256), 0, st, Zb.as<double>(), nb, s,
+                         fac.as<double>(), uu.as<double>(), inv_c, rsu.as<double>(), p1.as<double>(), p2.as<double>());
+      FLGP_TRY(check_launch("nys_exp_rows_kernel"));
+    } else {
+      FLGP_TRY((launch_sim<1>(st, dpad, dX + x0, nb, ldx, d, Ut.as<double>(), uu.as<double>(), s, inv_c, rsu.as<double>(),
+                              Zb.as<double>(), nb, p1.as<double>(), p2.as<double>())));
+    }
     hipLaunchKernelGGL(nys_reduce_kernel, dim3(ceil_div(nb, 256)), dim3(256), 0, st, p1.as<double>(), p2.as<double>(), nchunk,
                        nb, 1e-9, rsx.as<double>(), s1.as<double>());
     hipLaunchKernelGGL(nys_factor_kernel, dim3(ceil_div(nb, 256)), dim3(256), 0, st, rsx.as<double>(), s1.as<double>(), nb,

@@ -439,6 +439,29 @@ def test_nystrom_eigenpair(oracle, n, d, s, a2, K, seed):
     rp.free()
 
 
+def test_nystrom_dot_products_both_routes_bit_identical(oracle):
+    """d > 32 takes its dot products from the MFMA GEMM, d <= 32 from scalar-operand FMA chains: the same chain, and the
+    row sums are added in the same order, so forcing either route gives the same bits (and both match the oracle)."""
+    from flgp_amd import _lib
+    L = _lib.lib()
+    rng = np.random.default_rng(11)
+    for n, d, s, K in [(1500, 40, 200, 12), (900, 9, 130, 8), (3000, 64, 257, 5)]:
+        X = rng.normal(size=(n, d)) / np.sqrt(d); U = X[rng.permutation(n)[:s]] + 0.01 * rng.normal(size=(s, d))
+        got = []
+        try:
+            for route in (0, 1):
+                L.flgp_set_tuning(b"nystrom_dot_gemm", route)
+                got.append(api.nystrom_eigenpair_cpp(X, U, 0.7, K))
+        finally:
+            L.flgp_set_tuning(b"nystrom_dot_gemm", -1)
+        np.testing.assert_array_equal(got[0].values, got[1].values)
+        np.testing.assert_array_equal(got[0].vectors, got[1].vectors)
+        vals, vecs = oracle.np_nystrom_eigenpair(X, U, 0.7, K)
+        np.testing.assert_allclose(got[0].values, vals, rtol=1e-10, atol=0)
+        sign = np.sign(np.sum(got[0].vectors * vecs, axis=0))
+        np.testing.assert_allclose(got[0].vectors[:, 0] * sign[0], vecs[:, 0], rtol=1e-11, atol=0)
+
+
 def test_nystrom_eigenpair_blocks_and_errors(oracle):
     """more rows than one row block of the extension holds; argument checks"""
     rng = np.random.default_rng(5)
