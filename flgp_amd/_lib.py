@@ -51,6 +51,7 @@ _SIGNATURES = {
     "flgp_eigenpair_vty": (c_int, [P, c_int, P, c_int, P, c_int, P]),
     "flgp_eigenpair_vc": (c_int, [P, c_int, P, c_int, P, c_int, P]),
     "flgp_eigenpair_free": (None, [P]),
+    "flgp_kmeans_lloyd": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, P, P, P]),
     "flgp_nystrom_eigenpair": (c_int, [P, c_int, c_int, P, c_int, c_double, c_int, P, P]),
     "flgp_nystrom_eigenpair_resident": (c_int, [P, c_int, c_int, P, c_int, c_double, c_int, P]),
     "flgp_heat_kernel_covariance": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, c_double, c_int,
@@ -62,6 +63,8 @@ _SIGNATURES = {
     "flgp_dev_anchor_rows": (c_int, [c_int]),
     "flgp_dev_anchor_prep": (c_int, [P, P, c_int, c_int, c_int, P, P]),
     "flgp_dev_nystrom_eigenpair": (c_int, [P, P, c_int, c_int, c_int, P, c_int, c_int, c_double, c_int, P, P, c_int]),
+    "flgp_dev_kmeans_lloyd": (c_int, [P, P, c_int, c_int, c_int, c_int, P, c_int, P, c_int, P, P]),
+    "flgp_dev_kmeans_init": (c_int, [P, P, c_int, c_int, c_int, P, c_int, P, c_int]),
     "flgp_dev_knn": (c_int, [P, P, c_int, c_int, c_int, P, P, c_int, c_int, P, P, c_int]),
     "flgp_dev_lae": (c_int, [P, P, c_int, c_int, c_int, P, c_int, c_int, P, c_int, P, P]),
     "flgp_dev_v_to_z": (c_int, [P, P, c_int, P]),

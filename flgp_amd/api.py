@@ -272,20 +272,39 @@ def nystrom_eigenpair_cpp(X, U, a2, K, resident=False):
     return EigenPair(values, vectors)
 
 
-def subsample_cpp(X, s, method="kmeans", nstart=1, rng=None):
-    """subsample_cpp (src/Utils.cpp:32-68).  Only ``method="random"`` exists outside R (rows drawn
-    without replacement by a numpy Generator instead of R's ``sample``); k-means anchors come
-    from R (or any other k-means) and are passed to this package as ``U``."""
-    del nstart
+def kmeans_lloyd(X, s, init_rows, iter_max=100):
+    """Lloyd k-means on the device (include/flgp_hip.h ``flgp_kmeans_lloyd``).  ``init_rows``: (nstart, s) or (s,) row
+    indices of the starting centres.  Returns (U (s x (d+1), sizes last), rounds, tot_withinss)."""
     X = _f64(X, "X")
+    rows = np.ascontiguousarray(np.atleast_2d(np.asarray(init_rows)), dtype=np.int32)
+    if rows.shape[1] != int(s):
+        raise ValueError("init_rows must hold s row indices per start")
+    n, d = X.shape
+    U = np.zeros((int(s), d + 1), order="F")
+    it = ctypes.c_int(); wss = ctypes.c_double()
+    check(_lib.lib().flgp_kmeans_lloyd(_ptr(X), n, d, int(s), _ptr(rows), rows.shape[0], int(iter_max), _ptr(U),
+                                       ctypes.byref(it), ctypes.byref(wss)))
+    return U, it.value, wss.value
+
+
+def subsample_cpp(X, s, method="kmeans", nstart=1, rng=None):
+    """subsample_cpp (src/Utils.cpp:32-68).  ``"random"``: rows drawn without replacement (a numpy Generator in place
+    of R's ``sample``).  ``"lloyd"``: k-means on the device from ``nstart`` random starts, iter.max = 100 -- same output
+    contract as the reference's ``"kmeans"`` (centres + sizes), different algorithm (R's is Hartigan-Wong on R's
+    RNG and cannot be reproduced outside R).  ``"kmeans"`` / ``"minibatchkmeans"`` themselves stay in R: compute the
+    anchors there and pass them as ``U``."""
+    X = _f64(X, "X")
+    rng = np.random.default_rng(0) if rng is None else rng
     if method == "random":
-        rng = np.random.default_rng(0) if rng is None else rng
         rows = rng.choice(X.shape[0], size=int(s), replace=False)
         return np.asfortranarray(X[rows, :])
+    if method == "lloyd":
+        rows = np.stack([rng.choice(X.shape[0], size=int(s), replace=False) for _ in range(max(1, int(nstart)))])
+        return kmeans_lloyd(X, s, rows, iter_max=100)[0]
     if method in ("kmeans", "minibatchkmeans"):
         raise NotImplementedError(
             f"subsample=\"{method}\" is R's stats::kmeans / ClusterR (outside the accelerated path): "
-            "compute the anchors there and pass them as U (s x (d+1), cluster sizes last)")
+            "compute the anchors there and pass them as U (s x (d+1), cluster sizes last), or use subsample=\"lloyd\"")
     raise FlgpError(-3, "The subsample method is not supported!")
 
 

@@ -403,6 +403,49 @@ extern "C" int flgp_heat_kernel_spectrum_resident(const double *X_all, int n, in
   return FLGP_OK;
 }
 
+// ---- anchors by Lloyd k-means on the device (kmeans.hip)
+extern "C" int flgp_dev_kmeans_lloyd(void *stream, const double *dX, int n, int ldx, int d, int s, double *dC, int ldc,
+                                     double *d_size, int iter_max, int *iters_out, double *withinss_out);
+extern "C" int flgp_dev_kmeans_init(void *stream, const double *dX, int n, int ldx, int d, const int *d_rows, int s,
+                                    double *dC, int ldc);
+
+extern "C" int flgp_kmeans_lloyd(const double *X, int n, int d, int s, const int *init_rows, int nstart, int iter_max,
+                                 double *U_out, int *iters_out, double *withinss_out) {
+  FLGP_REQUIRE(X && init_rows && U_out, "kmeans_lloyd: null pointer");
+  FLGP_REQUIRE(n >= 1 && d >= 1 && s >= 1 && s <= n && nstart >= 1 && iter_max >= 1,
+               "kmeans_lloyd: need 1 <= s <= n, nstart >= 1, iter_max >= 1");
+  for (long a = 0; a < (long)nstart * s; ++a)
+    FLGP_REQUIRE(init_rows[a] >= 0 && init_rows[a] < n, "kmeans_lloyd: init_rows[%ld]=%d out of range", a, init_rows[a]);
+  Stream st;
+  FLGP_TRY(st.create());
+  DevBuf dX, dC, dbest, drows;
+  FLGP_TRY(dX.alloc(sizeof(double) * (size_t)n * d));
+  FLGP_TRY(dC.alloc(sizeof(double) * (size_t)s * (d + 1)));
+  FLGP_TRY(drows.alloc(sizeof(int) * (size_t)nstart * s));
+  if (nstart > 1) FLGP_TRY(dbest.alloc(sizeof(double) * (size_t)s * (d + 1)));
+  FLGP_TRY(h2d(dX.p, X, sizeof(double) * (size_t)n * d, st.s));
+  FLGP_TRY(h2d(drows.p, init_rows, sizeof(int) * (size_t)nstart * s, st.s));
+  double best = 0.0;
+  int best_it = 0;
+  for (int j = 0; j < nstart; ++j) {
+    double *C = dC.as<double>();
+    FLGP_TRY(flgp_dev_kmeans_init(st.s, dX.as<double>(), n, n, d, drows.as<int>() + (size_t)j * s, s, C, s));
+    int it = 0;
+    double wss = 0.0;
+    FLGP_TRY(flgp_dev_kmeans_lloyd(st.s, dX.as<double>(), n, n, d, s, C, s, C + (size_t)s * d, iter_max, &it,
+                                   (nstart > 1 || withinss_out) ? &wss : nullptr));
+    if (j == 0 || wss < best) {        // stats::kmeans keeps the start with the smallest tot.withinss
+      best = wss; best_it = it;
+      if (nstart > 1) FLGP_HIP(hipMemcpyAsync(dbest.p, dC.p, sizeof(double) * (size_t)s * (d + 1), hipMemcpyDeviceToDevice, st.s));
+    }
+  }
+  FLGP_TRY(d2h(U_out, nstart > 1 ? dbest.p : dC.p, sizeof(double) * (size_t)s * (d + 1), st.s));
+  FLGP_HIP(hipStreamSynchronize(st.s));
+  if (iters_out) *iters_out = best_it;
+  if (withinss_out) *withinss_out = best;
+  return FLGP_OK;
+}
+
 // ---- Nystrom-extension spectrum (reference src/Fit.cpp:244-289)
 extern "C" int flgp_dev_nystrom_eigenpair(void *stream, const double *dX, int n, int ldx, int d, const double *dU, int s,
                                           int ldu, double a2, int K, double *d_values, double *d_vectors, int ldv);

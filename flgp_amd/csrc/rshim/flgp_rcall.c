@@ -14,7 +14,7 @@
  * Division of labour, as in the reference:
  *   - R owns its objects; inputs are read in place (REAL()/INTEGER() are exactly the column-
  *     major buffers the C ABI wants), outputs are freshly allocated R objects;
- *   - subsampling (subsample_cpp, src/Utils.cpp:32-68) stays in R: stats::kmeans,
+ *   - subsampling (subsample_cpp, src/Utils.cpp:32-68) stays in R ("lloyd" is an added device method): stats::kmeans,
  *     ClusterR::MiniBatchKmeans and sample() are called back from here on the main R thread;
  *   - errors: the C ABI returns a status and a message; this file raises them with Rf_error
  *     (the reference: Rcpp::stop -> R condition).  Only R-managed memory (PROTECT / R_alloc) is
@@ -129,6 +129,24 @@ static SEXP subsample(SEXP X, int s, const char *method, int nstart) {
     for (int i = 0; i < s; ++i) cnt[i] = 0.0;
     for (int i = 0; i < n; ++i) cnt[lab[i]] += 1.0;
     UNPROTECT(8);
+    return U;
+  }
+  if (strcmp(method, "lloyd") == 0) {
+    /* extension: Lloyd k-means on the device, nstart starts drawn with base::sample as stats::kmeans
+     * draws its own; same s x (d+1) result as "kmeans", iter.max = 100 (src/Utils.cpp:41) */
+    if (nstart < 1) nstart = 1;
+    int *rows = (int *)R_alloc((size_t)nstart * s, sizeof(int));
+    for (int j = 0; j < nstart; ++j) {
+      SEXP args = R_NilValue;
+      args = PROTECT(Rf_cons(Rf_ScalarInteger(s), args));
+      args = PROTECT(Rf_cons(Rf_ScalarInteger(n), args));
+      SEXP draw = PROTECT(Rf_coerceVector(call_in_ns("base", "sample", args), INTSXP));
+      for (int i = 0; i < s; ++i) rows[(size_t)j * s + i] = INTEGER(draw)[i] - 1;
+      UNPROTECT(3);
+    }
+    SEXP U = PROTECT(Rf_allocMatrix(REALSXP, s, d + 1));
+    chk(flgp_kmeans_lloyd(REAL(X), n, d, s, rows, nstart, 100, REAL(U), NULL, NULL));
+    UNPROTECT(1);
     return U;
   }
   Rf_error("The subsample method is not supported!"); /* src/Utils.cpp:64 */

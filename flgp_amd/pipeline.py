@@ -155,6 +155,15 @@ class HipStages:
                                       V1.data_ptr(), n1, None, 0, n1, H.data_ptr(), n0, work.data_ptr()))
         return H
 
+    def nystrom(self, X, U, a2, K):  # X: (d, n_loc), U: (d, s) -> values (K,), vectors (K, n_loc)
+        d, n = X.shape
+        s = U.shape[1]
+        values = self.empty((K,)); vectors = self.empty((K, max(n, 1)))
+        if n:
+            _lib.check(self.L.flgp_dev_nystrom_eigenpair(self._st(), X.data_ptr(), n, n, d, U.data_ptr(), s, s, float(a2), int(K),
+                                                         values.data_ptr(), vectors.data_ptr(), n))
+        return values, vectors
+
     # -- plumbing used by the driver (no arithmetic of the path)
     def bincount(self, idx_row, s):
         return torch.bincount(idx_row.to(torch.int64), minlength=s).to(torch.float64)
@@ -331,3 +340,15 @@ class HeatKernelPath:
         if keep:
             res.ell_idx, res.ell_val, res.knn_idx = ell_idx, ell_val, knn_idx
         return res
+
+
+class NystromPath(HeatKernelPath):
+    """The Nystrom-extension spectrum (reference src/Fit.cpp:244-289) over row shards.  The extension is
+    row-local and the anchor side (s x s similarity, its top-K eigenpairs) is a deterministic function of the anchors
+    alone, so every rank computes it for itself: after the anchor all-gather there is no exchange at all, and the
+    stacked per-rank ``vectors`` are, bit for bit, the single-rank result."""
+
+    def run_nystrom(self, X_loc, U, a2: float, K: int):
+        """X_loc: (d, n_loc) local rows; U: (d, s) anchors as returned by :meth:`gather_anchors`.
+        Returns (values (K,), vectors (K, n_loc))."""
+        return self.stages.nystrom(X_loc, U, a2, K)

@@ -456,3 +456,33 @@ def np_nystrom_eigenpair(X_all, U, a2, K):
     W_XU = A_XU / (A_XU.sum(1) + 1e-9)[:, None]                             # :286-287
     vectors = (W_XU @ V) / (np.abs(values) + 1e-9)[None, :]                 # :289
     return values, vectors
+
+
+def np_kmeans_lloyd(X, init_rows, iter_max=100):
+    """Lloyd k-means with the operation order of flgp_amd/csrc/kmeans.hip -- NOT the reference's
+    stats::kmeans (src/Utils.cpp:36-45: Hartigan-Wong inside R), which cannot be restated outside R.  Assignment is
+    ``knn(X, C, 1)`` (A.1 arithmetic, ties to the lower centre, as src/Utils.cpp:59 does for the sizes); a centre is the
+    row-ordered sum of its points divided by their count; an empty centre keeps its position with size 0.
+    Returns (U (s x (d+1), sizes last), rounds)."""
+    X = _f64(X)
+    n, d = X.shape
+    C = np.asfortranarray(X[np.asarray(init_rows, dtype=np.int64), :])
+    s = C.shape[0]
+    size = np.zeros(s)
+    prev = np.full(n, -1, dtype=np.int32)
+    it = 0
+    while True:
+        lab = knn(X, C, 1)[:, 0]
+        if np.array_equal(lab, prev):
+            break
+        prev = lab.copy()
+        sums = np.zeros((s, d))
+        np.add.at(sums, lab, X)                       # unbuffered: rows are added in ascending order
+        cnt = np.bincount(lab, minlength=s)
+        keep = cnt > 0
+        C = np.asfortranarray(np.where(keep[:, None], sums / np.maximum(cnt, 1)[:, None], C))
+        size = cnt.astype(np.float64)
+        it += 1
+        if it >= iter_max:
+            break
+    return np.asfortranarray(np.hstack([C, size[:, None]])), it

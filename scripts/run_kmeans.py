@@ -1,0 +1,11 @@
+"""Device Lloyd k-means at bench size: python scripts/run_kmeans.py [n d s iter_max]"""
+import sys, time, numpy as np
+sys.path.insert(0, ".")
+from flgp_amd import api, synth
+n, d, s, itmax = (int(v) for v in (sys.argv[1:5] + ["1000000", "16", "5000", "100"][len(sys.argv) - 1:]))
+X = synth.gaussian_mixture(n, d, components=16, seed=20241022)
+rows = np.random.default_rng(0).choice(n, size=s, replace=False)
+for rep in range(2):
+    t0 = time.perf_counter(); U, it, wss = api.kmeans_lloyd(X, s, rows, iter_max=itmax); t1 = time.perf_counter()
+    print(f"n={n} d={d} s={s}: {it} rounds, {1e3*(t1-t0):.1f} ms ({1e3*(t1-t0)/max(it,1):.2f} ms/round incl. upload), wss {wss:.6e}, "
+          f"sizes min {U[:, d].min():.0f} max {U[:, d].max():.0f}", flush=True)

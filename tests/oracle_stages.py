@@ -76,6 +76,10 @@ class OracleStages:
         H = (_np_cm(V0) * w[None, :]) @ _np_cm(V1).T
         return _t_cm(H)
 
+    def nystrom(self, X, U, a2, K):
+        vals, vecs = O.np_nystrom_eigenpair(_np_cm(X), _np_cm(U), a2, K)
+        return torch.from_numpy(vals.copy()), _t_cm(vecs)
+
     def bincount(self, idx_row, s):
         return torch.bincount(idx_row.to(torch.int64), minlength=s).to(torch.float64)
 

@@ -462,6 +462,77 @@ def test_nystrom_dot_products_both_routes_bit_identical(oracle):
         np.testing.assert_allclose(got[0].vectors[:, 0] * sign[0], vecs[:, 0], rtol=1e-11, atol=0)
 
 
+def test_nystrom_row_shards_bit_identical(oracle):
+    """pipeline.NystromPath: the extension of a row shard is the same bits as those rows of the whole extension
+    (every output element is one k-ascending chain wherever its tile sits), so sharding rows over GPUs needs no
+    exchange beyond the anchors."""
+    import torch
+    from flgp_amd.pipeline import HipStages, NystromPath
+    st = HipStages("cuda:0")
+    path = NystromPath(st)
+    rng = np.random.default_rng(17)
+    n, d, s, K = 5000, 5, 300, 20
+    X = rng.normal(size=(n, d)); U = X[rng.permutation(n)[:s]]
+    Xt = torch.from_numpy(np.ascontiguousarray(X.T)).cuda(); Ut = torch.from_numpy(np.ascontiguousarray(U.T)).cuda()
+    vals, vecs = path.run_nystrom(Xt, Ut, 1.3, K)
+    ep = api.nystrom_eigenpair_cpp(X, U, 1.3, K)
+    np.testing.assert_array_equal(vals.cpu().numpy(), ep.values)
+    np.testing.assert_array_equal(vecs.cpu().numpy().T, ep.vectors)
+    for lo, hi in [(0, 1777), (1777, 5000), (4999, 5000)]:
+        v2, w2 = path.run_nystrom(Xt[:, lo:hi].contiguous(), Ut, 1.3, K)
+        np.testing.assert_array_equal(v2.cpu().numpy(), ep.values)
+        np.testing.assert_array_equal(w2.cpu().numpy().T, ep.vectors[lo:hi])
+
+
+@pytest.mark.parametrize("n,d,s,iter_max,seed", [(1200, 2, 4, 100, 0), (5000, 3, 60, 100, 1), (3000, 16, 200, 100, 2),
+                                                  (4000, 7, 129, 3, 3), (900, 33, 50, 100, 4), (64, 1, 64, 5, 5)])
+def test_kmeans_lloyd_bit_exact(oracle, n, d, s, iter_max, seed):
+    """Lloyd k-means on the device against its restatement -- labels come from the bit-exact k-NN kernel and
+    the centre sums are taken in row order, so centres, sizes and the number of rounds all agree exactly."""
+    rng = np.random.default_rng(seed)
+    X = rng.normal(size=(n, d)) + 4.0 * rng.integers(0, 3, size=(n, 1))
+    rows = rng.choice(n, size=s, replace=False)
+    Uo, ito = oracle.np_kmeans_lloyd(X, rows, iter_max)
+    U, it, wss = api.kmeans_lloyd(X, s, rows, iter_max=iter_max)
+    assert it == ito
+    np.testing.assert_array_equal(U, Uo)
+    assert U[:, d].sum() == n
+    if it < iter_max:                                # converged: wss is the objective at the returned centres
+        lab = oracle.knn(X, U[:, :d], 1)[:, 0]
+        ref = ((X - U[lab, :d]) ** 2).sum()
+        assert abs(wss - ref) <= 1e-9 * ref
+
+
+def test_kmeans_lloyd_duplicates_nstart_and_errors(oracle):
+    rng = np.random.default_rng(9)
+    X = np.vstack([rng.normal(size=(300, 2)) + c for c in ([0, 0], [8, 0], [0, 8], [8, 8])])
+    # two starting centres on the same point: the higher index never wins a tie, keeps its position, size 0
+    Xd = X.copy(); Xd[7] = Xd[3]
+    rows = np.array([3, 7, 400, 700])
+    for iter_max in (1, 100):
+        Uo, ito = oracle.np_kmeans_lloyd(Xd, rows, iter_max)
+        U, it, _ = api.kmeans_lloyd(Xd, 4, rows, iter_max=iter_max)
+        np.testing.assert_array_equal(U, Uo)
+        assert it == ito
+        if iter_max == 1:
+            assert U[1, 2] == 0 and np.array_equal(U[1, :2], Xd[3])
+    # nstart: the start with the smaller objective wins (a start with all centres in one blob loses)
+    bad = np.array([0, 1, 2, 4]); good = np.array([0, 300, 600, 900])
+    Ub, _, wb = api.kmeans_lloyd(X, 4, bad); Ug, _, wg = api.kmeans_lloyd(X, 4, good)
+    U2, _, w2 = api.kmeans_lloyd(X, 4, np.stack([bad, good]))
+    assert w2 == min(wb, wg)
+    np.testing.assert_array_equal(U2, Ug if wg <= wb else Ub)
+    # the mirror of subsample_cpp and the path on its anchors
+    U = api.subsample_cpp(X, 40, method="lloyd", nstart=2, rng=np.random.default_rng(1))
+    assert U.shape == (40, 3) and U[:, 2].sum() == 1200
+    H = api.heat_kernel_covariance_cpp(X[:100], X[100:], 40, 3, 5.0, 10, dict(kernel="lae", gl="cluster-normalized", root=True), 1, 0.1, U=U)
+    assert H.shape == (1200, 100) and np.isfinite(H).all()
+    with pytest.raises(api.FlgpError):
+        api.kmeans_lloyd(X, 4, np.array([0, 1, 2, 1200]))          # row out of range
+    with pytest.raises(api.FlgpError):
+        api.kmeans_lloyd(X[:3], 4, np.array([0, 1, 2, 2]))          # s > n
+
+
 def test_nystrom_eigenpair_blocks_and_errors(oracle):
     """more rows than one row block of the extension holds; argument checks"""
     rng = np.random.default_rng(5)

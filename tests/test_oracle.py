@@ -153,6 +153,23 @@ def test_nystrom_restatement_properties(oracle):
     np.testing.assert_allclose(P @ vecs[:s], vecs[:s] * vals, atol=1e-6)
 
 
+def test_kmeans_lloyd_restatement(oracle):
+    """np_kmeans_lloyd: a fixed point of assign/update -- every centre is the mean of the points nearest to it, sizes
+    count them, and well-separated blobs are recovered whatever rows it starts from."""
+    rng = np.random.default_rng(3)
+    cen = np.array([[0, 0], [9, 0], [0, 9], [9, 9]], dtype=float)
+    X = np.vstack([rng.normal(size=(250, 2)) + c for c in cen])
+    U, it = oracle.np_kmeans_lloyd(X, np.array([0, 250, 500, 750]), 100)
+    assert 1 <= it < 100 and U[:, 2].sum() == 1000
+    lab = oracle.knn(X, U[:, :2], 1)[:, 0]
+    for c in range(4):
+        np.testing.assert_allclose(U[c, :2], X[lab == c].mean(0), rtol=0, atol=1e-12)
+        assert U[c, 2] == (lab == c).sum() == 250
+    assert np.abs(U[:, :2] - cen).max() < 0.3
+    U1, it1 = oracle.np_kmeans_lloyd(X, np.array([0, 1, 2, 3]), 1)        # iter_max cuts the loop
+    assert it1 == 1
+
+
 def test_hk_c_vs_numpy(oracle):
     rng = np.random.default_rng(5)
     n, K = 37, 6

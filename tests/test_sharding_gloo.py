@@ -19,7 +19,7 @@ for p in (ROOT, HERE):
         sys.path.insert(0, p)
 
 from flgp_amd import synth  # noqa: E402
-from flgp_amd.pipeline import HeatKernelPath, PathConfig, shard_bounds  # noqa: E402
+from flgp_amd.pipeline import HeatKernelPath, NystromPath, PathConfig, shard_bounds  # noqa: E402
 
 N, D, S, R, K, M, T = 600, 3, 40, 4, 8, 50, 4.0
 
@@ -78,6 +78,38 @@ def test_two_ranks_match_one(tmp_path, kernel, gl):
     v1 = np.load(os.path.join(out, "vals_1_0.npy"))
     for r in range(2):
         np.testing.assert_allclose(np.load(os.path.join(out, f"vals_2_{r}.npy")), v1, rtol=1e-11)
+
+
+def _run_nystrom(rank, world, port, out):
+    from oracle_stages import OracleStages
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        lo, hi = shard_bounds(N, world, rank)
+        X, U_loc = _inputs(lo, hi)
+        path = NystromPath(OracleStages())
+        U = path.gather_anchors(torch.from_numpy(U_loc))
+        vals, vecs = path.run_nystrom(torch.from_numpy(np.ascontiguousarray(X.T)), U, 0.8, K)
+        np.save(os.path.join(out, f"nv_{world}_{rank}.npy"), vecs.numpy().T)
+        np.save(os.path.join(out, f"nl_{world}_{rank}.npy"), vals.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_nystrom_two_ranks_match_one(tmp_path):
+    """SURVEY 8f-3 over shards: one anchor all-gather, then nothing -- the stacked row blocks equal the single-rank
+    extension (the anchor-side eigensolve is replicated and deterministic; on the GPU the match is bit for bit,
+    tests/test_gpu_parity.py::test_nystrom_row_shards_bit_identical)."""
+    out = str(tmp_path)
+    for world in (1, 2):
+        mp.spawn(_run_nystrom, args=(world, _free_port(), out), nprocs=world, join=True)
+    V1 = np.load(os.path.join(out, "nv_1_0.npy"))
+    V2 = np.vstack([np.load(os.path.join(out, f"nv_2_{r}.npy")) for r in range(2)])
+    assert V1.shape == (N, K)
+    np.testing.assert_allclose(V2, V1, rtol=0, atol=1e-12 * np.abs(V1).max())   # numpy's GEMM may block rows differently
+    for r in range(2):
+        np.testing.assert_array_equal(np.load(os.path.join(out, f"nl_2_{r}.npy")), np.load(os.path.join(out, "nl_1_0.npy")))
 
 
 def test_single_process_matches_oracle_pipeline():
