@@ -809,23 +809,25 @@ __global__ void bs_onehot_kernel(const int *__restrict__ lab, int s, int p, doub
   OH[e] = (lab[i] == q) ? 1.0 : 0.0;
 }
 // Gp(i', k') = G(perm[i'], perm[k'])
-__global__ void bs_permute_kernel(const double *__restrict__ G, int ldg, int s, const int *__restrict__ perm,
-                                  double *__restrict__ Gp) {
-  const int kp = blockIdx.y;
-  const int ip = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ip >= s) return;
-  Gp[(size_t)kp * s + ip] = G[(size_t)perm[kp] * ldg + perm[ip]];
+// One workgroup per destination column: the source column (s doubles) is then pulled into one XCD's L2 once; split
+// over several workgroups it was fetched by every XCD they landed on (measured: 1.4 GB fetched for a 200 MB matrix).
+__global__ __launch_bounds__(1024) void bs_permute_kernel(const double *__restrict__ G, int ldg, int s,
+                                                          const int *__restrict__ perm, double *__restrict__ Gp) {
+  const int kp = blockIdx.x;
+  const double *src = G + (size_t)perm[kp] * ldg;
+  for (int ip = threadIdx.x; ip < s; ip += 1024) Gp[(size_t)kp * s + ip] = src[perm[ip]];
 }
-// non-zeros of the 16 x 128 block (k stage, i tile) of Gp; Gp(k, i) at k + i*s (symmetric)
+// non-zeros of the 16 x 128 block (k stage, i tile) of Gp; Gp(i, k) at i + k*s
 __global__ __launch_bounds__(128) void bs_count_kernel(const double *__restrict__ Gp, int s, int nstage,
                                                        int *__restrict__ cnt) {
   const int stage = blockIdx.x, tile = blockIdx.y;
   const int i = tile * 128 + threadIdx.x;
   int c = 0;
   if (i < s) {
-    const double *col = Gp + (size_t)i * s + (size_t)stage * 16;
+    // read as Gp(i, k) -- the element bs_pack_kernel copies out for the GEMM -- so lanes run along a column:
+    // 128 contiguous doubles per k (the transposed read fetched every line of the block 16 times over)
     for (int k = 0; k < 16; ++k)
-      if (stage * 16 + k < s && col[k] != 0.0) ++c;
+      if (stage * 16 + k < s && Gp[(size_t)(stage * 16 + k) * s + i] != 0.0) ++c;
   }
   __shared__ int red[128];
   red[threadIdx.x] = c;
@@ -1058,7 +1060,7 @@ static int bs_setup(hipStream_t st, const double *dG, int ldg, int s, int b, dou
   for (int q = 0; q <= p; ++q) start[q + 1] += start[q];
   for (int i = 0; i < s; ++i) perm[start[rank[lab[i]]]++] = i;   // stable counting sort by cluster rank
   FLGP_HIP(hipMemcpyAsync(bs.perm, perm.data(), sizeof(int) * s, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(bs_permute_kernel, dim3(ceil_div(s, 256), s), dim3(256), 0, st, dG, ldg, s, bs.perm, bs.Gp);
+  hipLaunchKernelGGL(bs_permute_kernel, dim3(s), dim3(1024), 0, st, dG, ldg, s, bs.perm, bs.Gp);
   hipLaunchKernelGGL(bs_count_kernel, dim3(nstage, ntile), dim3(128), 0, st, bs.Gp, s, nstage, sc.cnt);
   FLGP_TRY(check_launch("bs_count_kernel"));
   std::vector<int> cnt((size_t)ntile * nstage);
