@@ -147,14 +147,26 @@ __global__ void col_scale_kernel(const int *__restrict__ ell_idx, double *__rest
   val[e] = v;
 }
 
-__global__ void row_normalize_kernel(double *__restrict__ val, int n, int r) {
-  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  double *row = val + (size_t)i * r;
-  double rs = 0.0;
-  for (int a = 0; a < r; ++a) rs += row[a];        // ascending column order (src/Utils.cpp:210)
-  const double inv = 1.0 / (rs + 1e-9);
-  for (int a = 0; a < r; ++a) row[a] = inv * row[a];  // src/Utils.cpp:211
+// 256 rows per workgroup, staged through LDS: the rows are r doubles apart, so a thread walking its own row in
+// global memory touched a different cache line than its neighbours on every load (measured: 4x the bytes fetched and
+// written); the block's 256 r values are one contiguous run, read and written back coalesced.
+__global__ __launch_bounds__(256) void row_normalize_kernel(double *__restrict__ val, int n, int r) {
+  extern __shared__ double rn_rows[];
+  const long i0 = (long)blockIdx.x * 256;
+  const int rows = (n - i0 < 256) ? (int)(n - i0) : 256;
+  double *g = val + (size_t)i0 * r;
+  const int cnt = rows * r;
+  for (int e = threadIdx.x; e < cnt; e += 256) rn_rows[e] = g[e];
+  __syncthreads();
+  if ((int)threadIdx.x < rows) {
+    double *row = rn_rows + (size_t)threadIdx.x * r;
+    double rs = 0.0;
+    for (int a = 0; a < r; ++a) rs += row[a];        // ascending column order (src/Utils.cpp:210)
+    const double inv = 1.0 / (rs + 1e-9);
+    for (int a = 0; a < r; ++a) row[a] = inv * row[a];  // src/Utils.cpp:211
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < cnt; e += 256) g[e] = rn_rows[e];
 }
 
 // ----------------------------------------------------------------------------------------
@@ -162,6 +174,9 @@ __global__ void row_normalize_kernel(double *__restrict__ val, int n, int r) {
 // column's entries in ascending row order, loads GR = 64/r rows of A at a time (memory-level
 // parallelism) and applies them to the LDS row one row after the other, so that every
 // G(j1, j2) is summed in ascending row order: deterministic, and identical to the oracle.
+// Bound (measured at n = 1e6, s = 5000, r = 10: 2.4 ms): the LDS f64 atomics themselves, ~150 cycles per ds_add_f64
+// instruction per CU -- neither two groups of six steps in flight nor line-aligned packed row records (3.4 -> 1.3 GB
+// fetched) moved the time, so the loads are not what it waits for.
 // ----------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void gram_kernel(const int *__restrict__ ell_idx, const double *__restrict__ val,
                                                   int s, int r, const int *__restrict__ colptr,
@@ -392,7 +407,11 @@ extern "C" int flgp_dev_col_scale(void *stream, const int *d_ell_idx, double *d_
 
 extern "C" int flgp_dev_row_normalize(void *stream, double *d_ell_val, int n, int r) {
   if (n == 0) return FLGP_OK;
-  hipLaunchKernelGGL(row_normalize_kernel, dim3(ceil_div(n, 256)), dim3(256), 0, (hipStream_t)stream, d_ell_val,
+  FLGP_REQUIRE(r >= 1 && r <= FLGP_RMAX, "row_normalize: r = %d outside 1..%d", r, FLGP_RMAX);
+  const size_t lds = sizeof(double) * 256 * (size_t)r;
+  if (lds > 48 * 1024)
+    FLGP_HIP(hipFuncSetAttribute((const void *)row_normalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(row_normalize_kernel, dim3(ceil_div(n, 256)), dim3(256), lds, (hipStream_t)stream, d_ell_val,
                      n, r);
   return check_launch("row_normalize_kernel");
 }
