@@ -42,7 +42,18 @@ __global__ void csc_colscan_kernel(int *__restrict__ hist, int nchunks, int s, i
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= s) return;
   int run = 0;
-  for (int c = 0; c < nchunks; ++c) {
+  // 16 loads in flight per thread: one load, one store, one add at a time (the compiler cannot move a load above
+  // the preceding store to the same array) made each of the ~2000 steps a full memory round trip
+  constexpr int CB = 16;
+  int c = 0;
+  for (; c + CB <= nchunks; c += CB) {
+    int h[CB];
+#pragma unroll
+    for (int u = 0; u < CB; ++u) h[u] = hist[(size_t)(c + u) * s + j];
+#pragma unroll
+    for (int u = 0; u < CB; ++u) { hist[(size_t)(c + u) * s + j] = run; run += h[u]; }
+  }
+  for (; c < nchunks; ++c) {
     const int h = hist[(size_t)c * s + j];
     hist[(size_t)c * s + j] = run;
     run += h;
