@@ -77,6 +77,8 @@ _SIGNATURES = {
     "flgp_dev_col_scale": (c_int, [P, P, P, c_int, c_int, P, P, c_int]),
     "flgp_dev_row_normalize": (c_int, [P, P, c_int, c_int]),
     "flgp_dev_gram": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, c_int]),
+    "flgp_dev_sym_pack": (c_int, [P, P, c_int, c_int, P]),
+    "flgp_dev_sym_unpack": (c_int, [P, P, c_int, P, c_int]),
     "flgp_dev_eig_workspace": (c_size_t, [c_int, c_int]),
     "flgp_dev_eig_topk": (c_int, [P, P, c_int, c_int, c_int, c_double, P, P, c_int, P, c_size_t, P]),
     "flgp_dev_u_recover_workspace": (c_size_t, [c_int, c_int]),

@@ -441,6 +441,50 @@ extern "C" int flgp_dev_gram(void *stream, const int *d_ell_idx, const double *d
   return check_launch("gram_kernel");
 }
 
+// ---- upper triangle of a symmetric matrix as one contiguous run (exchange 3 of the row-sharded path sends s(s+1)/2
+// doubles instead of s^2; mirroring after the reduction also makes G symmetric bit for bit, which a ring all-reduce
+// of the full square does not: (i,j) and (j,i) travel in different chunks and are added in different rank orders).
+// Column j's rows 0..j sit at packed[j(j+1)/2 ..].
+__global__ __launch_bounds__(256) void sym_pack_kernel(const double *__restrict__ G, int ldg, int s, double *__restrict__ packed) {
+  const int j = blockIdx.y;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i <= j) packed[(size_t)j * (j + 1) / 2 + i] = G[(size_t)j * ldg + i];
+}
+// 32 x 32 tiles (ti <= tj): the upper tile is copied, its mirror image written through an LDS transpose
+__global__ __launch_bounds__(256) void sym_unpack_kernel(const double *__restrict__ packed, int s, double *__restrict__ G, int ldg) {
+  __shared__ double tile[32][33];
+  const int ti = blockIdx.x, tj = blockIdx.y;
+  if (ti > tj) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int c = ty; c < 32; c += 8) {
+    const int i = ti * 32 + tx, j = tj * 32 + c;
+    double v = 0.0;
+    if (i < s && j < s) {
+      v = (i <= j) ? packed[(size_t)j * (j + 1) / 2 + i] : packed[(size_t)i * (i + 1) / 2 + j];   // i > j only on diagonal tiles
+      G[(size_t)j * ldg + i] = v;
+    }
+    tile[c][tx] = v;
+  }
+  __syncthreads();
+  if (ti == tj) return;
+  for (int c = ty; c < 32; c += 8) {
+    const int i = tj * 32 + tx, j = ti * 32 + c;     // element (i, j) of the lower tile = (j, i) of the upper one
+    if (i < s && j < s) G[(size_t)j * ldg + i] = tile[tx][c];
+  }
+}
+
+extern "C" int flgp_dev_sym_pack(void *stream, const double *dG, int ldg, int s, double *d_packed) {
+  FLGP_REQUIRE(s >= 1 && ldg >= s, "sym_pack: bad shape");
+  hipLaunchKernelGGL(sym_pack_kernel, dim3(ceil_div(s, 256), s), dim3(256), 0, (hipStream_t)stream, dG, ldg, s, d_packed);
+  return check_launch("sym_pack_kernel");
+}
+extern "C" int flgp_dev_sym_unpack(void *stream, const double *d_packed, int s, double *dG, int ldg) {
+  FLGP_REQUIRE(s >= 1 && ldg >= s, "sym_unpack: bad shape");
+  const int nt = ceil_div(s, 32);
+  hipLaunchKernelGGL(sym_unpack_kernel, dim3(nt, nt), dim3(256), 0, (hipStream_t)stream, d_packed, s, dG, ldg);
+  return check_launch("sym_unpack_kernel");
+}
+
 extern "C" size_t flgp_dev_u_recover_workspace(int s, int K) { return sizeof(double) * (size_t)s * K + 256; }
 
 extern "C" int flgp_dev_u_recover(void *stream, const int *d_ell_idx, const double *d_ell_val, int n, int r,

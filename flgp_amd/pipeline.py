@@ -8,7 +8,7 @@ SURVEY.md §8(e):
 
   1. all-gather of the anchor sets (+ all-reduce of the 1-NN cluster counts),
   2. all-reduce(sum) of the column sums of Z  (8 s bytes, twice),
-  3. all-reduce(sum) of the Gram partials     (8 s^2 bytes -- the one real exchange);
+  3. all-reduce(sum) of the Gram partials     (upper triangle, 4 s(s+1) bytes -- the one real exchange);
      the s x s eigensolve then runs replicated, with no further communication,
   4. sum-all-reduce of the zero-padded training block V[0:m] (m x K): a broadcast from
      its owners that needs no ownership bookkeeping.
@@ -121,6 +121,17 @@ class HipStages:
         G = self.empty((s, s))
         _lib.check(self.L.flgp_dev_gram(self._st(), ell_idx.data_ptr(), ell_val.data_ptr(), n, s, r, csc["colptr"].data_ptr(),
                                         csc["pos"].data_ptr(), G.data_ptr(), s))
+        return G
+
+    def sym_pack(self, G):
+        s = G.shape[0]
+        p = self.empty((s * (s + 1) // 2,))
+        _lib.check(self.L.flgp_dev_sym_pack(self._st(), G.data_ptr(), s, s, p.data_ptr()))
+        return p
+
+    def sym_unpack(self, p, G):
+        s = G.shape[0]
+        _lib.check(self.L.flgp_dev_sym_unpack(self._st(), p.data_ptr(), s, G.data_ptr(), s))
         return G
 
     def eig_topk(self, G, K, tol=0.0):
@@ -319,7 +330,9 @@ class HeatKernelPath:
         S.col_scale(ell_idx, ell_val, c2, None, 1)
         tm.mark("laplacian")
         # k6: Gram, replicated top-K eigensolve
-        G = self._all_reduce(S.gram(ell_idx, ell_val, csc))                   # exchange 3
+        G = S.gram(ell_idx, ell_val, csc)
+        if self.dist and self.world > 1:                                      # exchange 3: the upper triangle only
+            G = S.sym_unpack(self._all_reduce(S.sym_pack(G)), G)
         tm.mark("gram")
         K = s if cfg.K < 0 else cfg.K
         eig, V, info = S.eig_topk(G, K)

@@ -57,6 +57,16 @@ class OracleStages:
     def gram(self, ell_idx, ell_val, csc):
         return torch.from_numpy(O.gram(ell_idx.numpy(), ell_val.numpy(), csc["s"]))
 
+    def sym_pack(self, G):
+        g = G.numpy(); s = g.shape[0]
+        return torch.from_numpy(np.concatenate([g[j, :j + 1] for j in range(s)]))     # (s, s) tensor == column-major: g[j] is column j
+
+    def sym_unpack(self, p, G):
+        s = G.shape[0]; v = p.numpy(); g = np.zeros((s, s)); o = 0
+        for j in range(s):
+            g[j, :j + 1] = v[o:o + j + 1]; g[:j + 1, j] = v[o:o + j + 1]; o += j + 1
+        return torch.from_numpy(g)
+
     def eig_topk(self, G, K, tol=0.0):
         w, V = np.linalg.eigh(G.numpy())
         w = w[::-1][:K].copy(); V = V[:, ::-1][:, :K]

@@ -214,6 +214,20 @@ def test_csc_colsum_gram_bit_exact(oracle, stages):
     np.testing.assert_array_equal(G, G.T)
 
 
+@pytest.mark.parametrize("s", [1, 31, 32, 257, 1000])
+def test_sym_pack_unpack(stages, s):
+    """exchange 3 sends the upper triangle of the Gram partials: pack / unpack are exact copies, and the unpacked
+    matrix is symmetric bit for bit whatever was below the diagonal before"""
+    rng = np.random.default_rng(s)
+    A = rng.normal(size=(s, s))                         # not symmetric: only the upper triangle may be read
+    G = torch.from_numpy(np.ascontiguousarray(A.T)).cuda()          # (s, s) tensor == column-major A
+    p = stages.sym_pack(G).cpu().numpy()
+    np.testing.assert_array_equal(p, np.concatenate([A[:j + 1, j] for j in range(s)]))
+    out = stages.sym_unpack(torch.from_numpy(p).cuda(), torch.full((s, s), np.nan, dtype=torch.float64, device="cuda")).cpu().numpy().T
+    ref = np.triu(A) + np.triu(A, 1).T
+    np.testing.assert_array_equal(out, ref)
+
+
 @pytest.mark.parametrize("M,N,Kd", [(128, 128, 16), (130, 257, 33), (1, 1, 1), (500, 40, 200), (64, 64, 5000), (300, 300, 7)])
 def test_gemm_f64(stages, M, N, Kd):
     rng = np.random.default_rng(M + N + Kd)
