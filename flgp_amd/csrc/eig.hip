@@ -355,6 +355,23 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
   };
 
   load_panel(B);
+  // The V panel is wanted only after the small eigenproblem is solved; its loads are issued now (registers) so that
+  // their L2 / fabric latency -- the panels were last written by other XCDs -- passes behind the Gram product and
+  // the Jacobi rounds instead of in front of the second apply.  b <= 64 VPF rows per lane, else loaded late as before.
+  constexpr int VPF = 8;
+  const bool v_early = b <= 64 * VPF;
+  double vreg[NLOC / 16][VPF];
+  if (v_early) {
+#pragma unroll
+    for (int cc_ = 0; cc_ < NLOC / 16; ++cc_) {
+      const int gc = gcol(wave + 16 * cc_);
+#pragma unroll
+      for (int m = 0; m < VPF; ++m) {
+        const int i = lane + 64 * m;
+        vreg[cc_][m] = (gc < b && i < b) ? V[(size_t)gc * ldb + i] : 0.0;
+      }
+    }
+  }
   __syncthreads();
   // ---- Gram block on the matrix cores
   if (wave < TILES * KP) {
@@ -451,7 +468,17 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
   __syncthreads();
   store_panel(B);
   __syncthreads();
-  load_panel(V);
+  if (v_early) {
+#pragma unroll
+    for (int cc_ = 0; cc_ < NLOC / 16; ++cc_)
+#pragma unroll
+      for (int m = 0; m < VPF; ++m) {
+        const int i = lane + 64 * m;
+        if (i < b) P[(size_t)(wave + 16 * cc_) * bp + i] = vreg[cc_][m];
+      }
+  } else {
+    load_panel(V);
+  }
   __syncthreads();
   apply_w();
   __syncthreads();

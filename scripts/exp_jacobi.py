@@ -6,13 +6,16 @@ sys.path.insert(0, ROOT)
 from flgp_amd import _lib
 from flgp_amd.pipeline import HipStages
 S = HipStages("cuda:0"); L = S.L
+for kv in sys.argv[1:]:
+    k, v = kv.split("=")
+    L.flgp_set_tuning(k.encode(), int(v))
 
 def q(name):
     c = ctypes.c_int(0); ms = ctypes.c_double(0); w = ctypes.c_double(0)
     L.flgp_prof_query(name.encode(), ctypes.addressof(c), ctypes.addressof(ms), ctypes.addressof(w))
     return c.value, ms.value
 
-for b in (256, 128, 512):
+for b in (256,):
     for kind in ("diagonal", "random"):
         rng = np.random.default_rng(0)
         if kind == "diagonal":
@@ -20,9 +23,16 @@ for b in (256, 128, 512):
         else:
             A = rng.normal(size=(b, b)); G = A @ A.T / b
         dG = torch.from_numpy(G).cuda()
-        S.eig_topk(dG, b)
-        L.flgp_prof_reset(); L.flgp_prof_enable(1)
-        eig, V, info = S.eig_topk(dG, b)
+        try:
+            S.eig_topk(dG, b)
+        except Exception:
+            pass
+        L.flgp_prof_reset(); L.flgp_prof_enable(2)
+        try:
+            eig, V, info = S.eig_topk(dG, b)
+            sw = info['outer_iterations']
+        except Exception as e:          # debug knobs that break convergence: 60 sweeps were run
+            sw = 60
         torch.cuda.synchronize(); L.flgp_prof_enable(0)
         c, ms = q("jacobi_eig")
-        print(f"b={b} {kind:9s}: jacobi_eig {ms:.3f} ms, sweeps={info['outer_iterations']}, per sweep {ms/max(info['outer_iterations'],1):.3f} ms", flush=True)
+        print(f"b={b} {kind:9s}: jacobi_eig {ms:.3f} ms, sweeps={sw}, per sweep {ms/max(sw,1):.3f} ms", flush=True)
