@@ -89,8 +89,9 @@ __global__ __launch_bounds__(256) void knn_kernel(const double *__restrict__ X, 
   constexpr int TA = knn_tile_anchors<DP>();
   constexpr bool USE_LDS = KS < DP;
   static_assert(TA % A == 0 && QC > A, "tile / queue geometry");
-  __shared__ double q_d[QC * P * NT];
-  __shared__ int q_j[QC * P * NT];
+  constexpr bool NN1 = RCAP == 1;     // r = 1 (Lloyd assignment, cluster counts): a running minimum, no queue
+  __shared__ double q_d[NN1 ? 1 : QC * P * NT];
+  __shared__ int q_j[NN1 ? 1 : QC * P * NT];
   __shared__ __attribute__((aligned(16))) double tile[USE_LDS ? TA * DP : 2];
 
   const int tid = threadIdx.x;
@@ -170,16 +171,22 @@ __global__ __launch_bounds__(256) void knn_kernel(const double *__restrict__ X, 
 #pragma unroll
         for (int p = 0; p < P; ++p) {
           const double D = __builtin_fma(-2.0, acc[p][a], xx[p]) + uuj;
-          if (D < top[p].thr()) {
+          if constexpr (NN1) {
+            const bool c = D < top[p].bd[0];            // strict: the lower index keeps a tie
+            top[p].bd[0] = c ? D : top[p].bd[0];
+            top[p].bi[0] = c ? j0 + jj + a : top[p].bi[0];
+          } else if (D < top[p].thr()) {
             q_d[(cnt[p] * P + p) * NT + tid] = D;
             q_j[(cnt[p] * P + p) * NT + tid] = j0 + jj + a;
             ++cnt[p];
           }
         }
       }
+      if constexpr (!NN1) {
 #pragma unroll
-      for (int p = 0; p < P; ++p) full |= (cnt[p] > QC - A);
-      if (__any(full)) drain();
+        for (int p = 0; p < P; ++p) full |= (cnt[p] > QC - A);
+        if (__any(full)) drain();
+      }
     }
   }
   drain();
@@ -335,6 +342,118 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(DP <= 32 ? 
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// r = 1 on the matrix cores (Lloyd's assignment step, the cluster counts of subsample_cpp): no list, no queue and
+// no turn through LDS.  The MFMA result layout gives lane (fk, fr) the dot products of points fk + 4 reg (reg 0..3)
+// of a 16-point block with anchor fr of a 16-anchor group; the lane keeps the running minimum of each of its
+// 4 x 4 (block, reg) points over the anchors of ITS residue class (fr mod 16), in ascending anchor order with a
+// strict '<' -- the lower index keeps a tie -- and the 16 lanes of a row merge their minima at the very end
+// (smaller distance, then smaller index).  Same arithmetic as everywhere: chain from C = 0, D = fma(-2, dot, |x|^2) + |u|^2.
+// (Measured why this exists: without any selection the VALU kernel still needs 4.4 ms per 1e6 x 5000 x 16 -- its LDS
+// broadcast operand reads, not the selection, are what it waits for.)
+// ------------------------------------------------------------------------------------------
+template <int DP>
+__global__ __launch_bounds__(128) void knn1_mfma_kernel(const double *__restrict__ X, int n, int ldx, int d,
+                                                        const double *__restrict__ Ut, const double *__restrict__ uu, int s,
+                                                        int *__restrict__ idx_out, double *__restrict__ dist_out) {
+  constexpr int NW = 2, TA = 64, TLD = TA + 1, NQ = DP / 4;
+  __shared__ double tile[DP * TLD];
+  __shared__ double xxs[NW][64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int fr = lane & 15, fk = lane >> 4;
+  const long pbase = (long)blockIdx.x * (64 * NW) + wave * 64;
+  {   // |x|^2 of point pbase + lane by the oracle's chain, handed to the lanes that need it through LDS
+    long i = pbase + lane;
+    if (i >= n) i = n - 1;
+    double acc = 0.0;
+#pragma unroll
+    for (int k = 0; k < DP; ++k) {
+      const double xk = (k < d) ? X[(size_t)k * ldx + i] : 0.0;
+      acc = (k == 0) ? xk * xk : __builtin_fma(xk, xk, acc);
+    }
+    xxs[wave][lane] = acc;
+  }
+  double xa[4][NQ];
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt) {
+    long i = pbase + pt * 16 + fr;
+    if (i >= n) i = n - 1;
+#pragma unroll
+    for (int q = 0; q < NQ; ++q) xa[pt][q] = (4 * q + fk < d) ? X[(size_t)(4 * q + fk) * ldx + i] : 0.0;
+  }
+  __syncthreads();
+  double xxp[4][4], bd[4][4];
+  int bj[4][4];
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      xxp[pt][reg] = xxs[wave][pt * 16 + fk + 4 * reg];
+      bd[pt][reg] = __builtin_inf();
+      bj[pt][reg] = 0x7fffffff;
+    }
+  const int s_pad = (s + 127) / 128 * 128;   // padded panel: zeros, |u|^2 = +inf (never below a minimum)
+  for (int j0 = 0; j0 < s_pad; j0 += TA) {
+    __syncthreads();
+    {
+      const double *src = Ut + (size_t)j0 * DP;
+      for (int e = tid; e < TA * DP; e += 64 * NW) tile[(e % DP) * TLD + e / DP] = src[e];
+    }
+    __syncthreads();
+#pragma unroll 1
+    for (int g = 0; g < TA / 16; ++g) {
+      double ub[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; ++q) ub[q] = tile[(4 * q + fk) * TLD + g * 16 + fr];
+      const int j = j0 + g * 16 + fr;
+      const double uuj = uu[j];
+#pragma unroll
+      for (int pt = 0; pt < 4; ++pt) {
+        kd4 acc = kd4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int q = 0; q < NQ; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(xa[pt][q], ub[q], acc, 0, 0, 0);
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) {
+          const double D = __builtin_fma(-2.0, acc[reg], xxp[pt][reg]) + uuj;
+          const bool c = D < bd[pt][reg];
+          bd[pt][reg] = c ? D : bd[pt][reg];
+          bj[pt][reg] = c ? j : bj[pt][reg];
+        }
+      }
+    }
+  }
+  // merge the 16 residue classes of every point: lanes fk*16 .. fk*16+15
+#pragma unroll
+  for (int pt = 0; pt < 4; ++pt)
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) {
+      double dmin = bd[pt][reg];
+      int jmin = bj[pt][reg];
+#pragma unroll
+      for (int m = 1; m < 16; m <<= 1) {
+        const double od = __shfl_xor(dmin, m, 64);
+        const int oj = __shfl_xor(jmin, m, 64);
+        const bool take = (od < dmin) || (od == dmin && oj < jmin);
+        dmin = take ? od : dmin;
+        jmin = take ? oj : jmin;
+      }
+      const long i = pbase + pt * 16 + fk + 4 * reg;
+      if (fr == 0 && i < n) {
+        idx_out[i] = jmin;
+        if (dist_out) dist_out[i] = dmin;
+      }
+    }
+}
+
+template <int DP>
+static int launch_knn1_mfma(hipStream_t st, const double *dX, int n, int ldx, int d, const double *dUt,
+                            const double *duu, int s, int *d_idx, double *d_dist) {
+  ProfScope ps("knn_kernel", st, 2.0 * (double)n * (double)s * (double)d);
+  hipLaunchKernelGGL((knn1_mfma_kernel<DP>), dim3(ceil_div(n, 128)), dim3(128), 0, st, dX, n, ldx, d, dUt, duu, s, d_idx,
+                     d_dist);
+  return check_launch("knn1_mfma_kernel");
+}
+
 template <int DP, int RCAP>
 static int launch_knn_mfma(hipStream_t st, const double *dX, int n, int ldx, int d, const double *dUt,
                            const double *duu, int s, int r, int *d_idx, double *d_dist, int ldo) {
@@ -404,6 +523,27 @@ extern "C" int flgp_dev_knn(void *stream, const double *dX, int n, int ldx, int 
   if (n == 0) return FLGP_OK;
   const int rcap = r <= 4 ? 4 : (r <= 8 ? 8 : (r <= 16 ? 16 : 32));
   const int variant = tuning("knn_variant", 0);
+  if (r == 1 && tuning("knn_nn1", 1)) {   // the 1-NN of Lloyd's assignment step and of the cluster counts
+    const int v1 = tuning("knn_nn1_variant", 0);
+    if (v1 == 0 || v1 == 5) {
+      if (dpad == 4) return launch_knn1_mfma<4>(st, dX, n, ldx, d, dUt, duu, s, d_idx, d_dist);
+      if (dpad == 8) return launch_knn1_mfma<8>(st, dX, n, ldx, d, dUt, duu, s, d_idx, d_dist);
+      if (dpad == 16) return launch_knn1_mfma<16>(st, dX, n, ldx, d, dUt, duu, s, d_idx, d_dist);
+      if (dpad == 32) return launch_knn1_mfma<32>(st, dX, n, ldx, d, dUt, duu, s, d_idx, d_dist);
+      if (dpad == 64) return launch_knn1_mfma<64>(st, dX, n, ldx, d, dUt, duu, s, d_idx, d_dist);
+    }
+    if (dpad == 4) return launch_knn<4, 1, 2, 4, 2, 12>(KNN_ARGS);
+    if (dpad == 8) return launch_knn<8, 1, 2, 4, 4, 12>(KNN_ARGS);
+    if (dpad == 16) {
+      if (v1 == 1) return launch_knn<16, 1, 1, 2, 8, 8>(KNN_ARGS);
+      if (v1 == 2) return launch_knn<16, 1, 1, 4, 8, 8>(KNN_ARGS);
+      if (v1 == 3) return launch_knn<16, 1, 2, 4, 8, 8>(KNN_ARGS);
+      if (v1 == 4) return launch_knn<16, 1, 4, 2, 8, 8>(KNN_ARGS);
+      return launch_knn<16, 1, 4, 2, 8, 8>(KNN_ARGS);
+    }
+    if (dpad == 32) return launch_knn<32, 1, 1, 2, 16, 8>(KNN_ARGS);
+    if (dpad == 64) return launch_knn<64, 1, 1, 2, 16, 8>(KNN_ARGS);
+  }
   // The matrix-core kernel wins once the distance itself dominates (measured, n = 4e5, s = 5000, r = 10:
   // d = 64 11.4 vs 18.8 ms, d = 32 5.4 vs 5.8 ms); at d <= 16 the selection is the larger half of either
   // kernel and the VALU kernel's three waves per SIMD hide its latencies better (d = 16: 6.7 vs 6.0 ms

@@ -81,6 +81,29 @@ def test_knn_both_kernels_bit_exact(oracle, mfma):
         L.flgp_set_tuning(b"knn_mfma", -1)
 
 
+@pytest.mark.parametrize("variant", [0, 6])
+def test_knn_one_neighbour_kernels_bit_exact(oracle, variant):
+    """r = 1 has its own kernels (running minima in the MFMA result layout, merged across 16 lanes at the end; or the
+    VALU kernel without its queue): indices AND distances equal the oracle's over every padded dimension, ragged sizes,
+    and exact ties (lower anchor index)."""
+    from flgp_amd import _lib
+    L = _lib.lib()
+    try:
+        L.flgp_set_tuning(b"knn_nn1_variant", variant)
+        for n, d, s in [(1000, 1, 130), (777, 3, 64), (513, 7, 129), (2049, 16, 1000), (300, 33, 70), (260, 64, 140), (3, 5, 3)]:
+            X, U0, _ = make_case(n, d, s, 1, seed=11 * n + d, with_sizes=False)
+            res = api.KNN_cpp(X, U0, 1, output=True)
+            oi, od = oracle.knn(X, U0, 1, output=True)
+            np.testing.assert_array_equal(res["ind_knn"], oi)
+            np.testing.assert_array_equal(res["distances_sp"].data.reshape(n, 1), od)
+        g = np.linspace(-1.0, 1.0, 5)
+        U = np.array([[a, b] for a in g for b in g] * 3 + [[0.0, 0.0]])         # every lattice point three times
+        X = np.array([[0.0, 0.0], [0.5, 0.5], [3.0, -3.0], [-1.0, 2.0], [0.25, -0.75]])
+        np.testing.assert_array_equal(api.KNN_cpp(X, U, 1)["ind_knn"], oracle.knn(X, U, 1))
+    finally:
+        L.flgp_set_tuning(b"knn_nn1_variant", 0)
+
+
 def test_knn_single_point(oracle):
     rng = np.random.default_rng(4)
     X = rng.normal(size=(1, 16)); U = rng.normal(size=(300, 16))
