@@ -105,7 +105,12 @@ __global__ __launch_bounds__(64) void lae_reg_kernel(const double *__restrict__ 
       }
     }
   }
-  // (each wave is its own workgroup and LDS operations of one wave complete in order: no barrier needed)
+  // Lane `sub == 0` of a group stored the block, the other lanes of the group read it: the hardware completes one
+  // wave's LDS operations in order, but without a fence the COMPILER may move those loads above the (to it,
+  // unrelated and conditional) stores -- it did for r <= 5 with two or four lanes per point, where everything is
+  // unrolled into registers: the lanes that did not store read stale LDS (scripts/sweep_lae.py).  The workgroup is
+  // this single wave, so the barrier costs nothing at run time.
+  __syncthreads();
   auto Gab = [&](int a, int b) -> double {
     const int lo = a < b ? a : b, hi = a < b ? b : a;
     return Gl[(lo * R - lo * (lo - 1) / 2 + (hi - lo)) * PTS + pl];

@@ -141,7 +141,9 @@ def test_v_to_z(oracle):
 
 
 @pytest.mark.parametrize("r,d", [(1, 2), (2, 2), (3, 2), (5, 3), (8, 16), (10, 16), (12, 4), (16, 3), (20, 2), (10, 64),
-                                 (10, 12), (10, 17), (10, 32), (10, 40), (7, 16), (9, 33), (13, 8), (16, 16), (14, 30)])
+                                 (10, 12), (10, 17), (10, 32), (10, 40), (7, 16), (9, 33), (13, 8), (16, 16), (14, 30),
+                                 # few anchors over several lanes per point: the shapes a missing fence broke (sweep_lae.py)
+                                 (2, 40), (3, 17), (4, 40), (5, 32), (5, 64), (6, 24), (8, 48), (2, 64), (11, 20), (16, 32)])
 def test_lae_bit_exact(oracle, r, d):
     n, s = 500, 64
     X, U0, _ = make_case(n, d, s, r, seed=31 * r + d, with_sizes=False)
