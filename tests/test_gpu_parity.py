@@ -209,6 +209,37 @@ def test_cross_similarity_se(oracle):
     np.testing.assert_allclose(Z.data.reshape(n, r), zn, rtol=1e-14, atol=0)   # exp() differs by a few ulp
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_random_shapes_whole_path(oracle, seed):
+    """One random configuration per seed (dimension, anchors, neighbours, rows, K, kernel, Laplacian, root, t) through
+    heat_kernel_covariance_cpp against the oracle -- the shapes nobody thought of listing (scripts/stress_parity.py is the
+    long version; it found the r <= 5, d > 16 LAE bug).  Degenerate inputs are left out: r = 1 (G is the identity), an SE
+    bandwidth far below the neighbour distances (Z underflows), K = s with few rows per anchor (singular values at
+    rounding level: their left vectors are arbitrary in the reference too)."""
+    rng = np.random.default_rng(1000 + seed)
+    d = int(rng.choice([1, 2, 3, 5, 8, 13, 16, 17, 32, 40, 64]))
+    s = int(rng.integers(12, 200))
+    r = int(rng.integers(2, min(s, 24) + 1))
+    n = int(rng.integers(max(4 * s, 50), 3000))
+    m = int(rng.integers(1, min(n, 200) + 1))
+    K = int(rng.integers(1, min(s, 40) + 1)) if rng.random() < 0.85 else -1
+    kernel = str(rng.choice(["lae", "se"])); gl = str(rng.choice(["rw", "normalized", "cluster-normalized"]))
+    root = bool(rng.integers(0, 2)); t = float(rng.choice([0.1, 1.0, 10.0]))
+    eps = float(rng.choice([0.5, 1.0, 3.0])) * np.sqrt(d)
+    X = rng.normal(size=(n, d)) + 3.0 * rng.integers(0, 3, size=(n, 1))
+    U0 = X[np.sort(rng.choice(n, size=s, replace=False))] + 1e-3 * rng.normal(size=(s, d))
+    lab = oracle.knn(X, U0, 1)[:, 0]
+    U = np.asfortranarray(np.hstack([U0, np.bincount(lab, minlength=s)[:, None].astype(float)]))
+    H = api.heat_kernel_covariance_cpp(X[:m], X[m:], s, r, t, K, dict(kernel=kernel, gl=gl, root=root), 1, eps, U=U)
+    Ho = oracle.heat_kernel_covariance(X[:m], X[m:], U, r, t, K=K, kernel=kernel, gl=gl, root=root, epsilon=eps)
+    err = np.abs(H - Ho).max() / np.abs(Ho).max()
+    if err >= 1e-7 and 0 < K < s:     # a cut through a cluster of eigenvalues is ill-posed: accept only with the gap shown
+        v, _ = oracle.heat_kernel_spectrum(np.asfortranarray(X), U, r, K + 1, kernel, gl, root, eps, "auto")
+        assert abs(v[K - 1] - v[K]) < 1e-6 * v[0], (err, v[K - 2:K + 1])
+    else:
+        assert err < 1e-7, (err, dict(n=n, d=d, s=s, r=r, m=m, K=K, kernel=kernel, gl=gl, root=root, t=t))
+
+
 def test_cluster_normalized_needs_sizes():
     X, U0, U = make_case(100, 2, 10, 3, seed=1)
     with pytest.raises(api.FlgpError) as e:
