@@ -1850,6 +1850,25 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   }
   if (info) { info[0] = it; info[1] = gprods; info[2] = 0; info[3] = ns_orths * 1000 + jac_orths; }
   if (!converged) {
+    // A spectrum the filter cannot split -- e.g. r = 1, where G is the identity up to the 1e-9 guards and the wanted
+    // and unwanted eigenvalues coincide -- never meets the residual test.  While the full decomposition is affordable
+    // (s <= 4096) it is taken instead, with its own workspace: any orthonormal basis of a degenerate eigenspace is a
+    // valid answer, and the Jacobi route always delivers one.
+    if (s <= 4096 && tuning("eig_dense_fallback", 1)) {
+      DevBuf fw, fvals, fV;
+      const size_t fb = eig_workspace_bytes(s, s);
+      FLGP_TRY(fw.alloc(fb));
+      FLGP_TRY(fvals.alloc(sizeof(double) * (size_t)s));
+      FLGP_TRY(fV.alloc(sizeof(double) * (size_t)s * s));
+      if (tuning("eig_verbose", 0)) fprintf(stderr, "[flgp eig] no convergence after %d outer iterations: full decomposition instead\n", max_it);
+      FLGP_TRY(flgp_dev_eig_topk(stream, dG, ldg, s, s, tol, fvals.as<double>(), fV.as<double>(), s, fw.p, fb, nullptr));
+      FLGP_HIP(hipMemcpyAsync(d_values, fvals.p, sizeof(double) * K, hipMemcpyDeviceToDevice, st));
+      FLGP_HIP(hipMemcpy2DAsync(dV, sizeof(double) * (size_t)ldv, fV.p, sizeof(double) * (size_t)s, sizeof(double) * (size_t)s, K,
+                                hipMemcpyDeviceToDevice, st));
+      FLGP_HIP(stream_wait(st));
+      if (info) info[2] = 1;
+      return FLGP_OK;
+    }
     set_error("eigensolver: %d of the residuals still above %.1e after %d outer iterations", K, tol, max_it);
     return FLGP_ERR_NOCONV;
   }

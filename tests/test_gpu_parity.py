@@ -332,6 +332,27 @@ def test_eig_topk(stages, s, K):
         assert np.linalg.norm(Vr - V @ (V.T @ Vr)) < 1e-7
 
 
+def test_eig_degenerate_spectrum_falls_back(oracle, stages):
+    """A spectrum the Chebyshev filter cannot split (r = 1 makes G the identity up to the 1e-9 guards) ends in the
+    full Jacobi decomposition instead of an error: any orthonormal basis of the degenerate eigenspace is valid."""
+    s, K = 600, 30
+    rng = np.random.default_rng(4)
+    Q, _ = np.linalg.qr(rng.normal(size=(s, s)))
+    G = (Q * (1.0 + 1e-10 * rng.normal(size=s))) @ Q.T
+    G = 0.5 * (G + G.T)
+    eig, V, info = stages.eig_topk(torch.from_numpy(G).cuda(), K)
+    V = V.cpu().numpy().T; lam = eig.cpu().numpy()
+    assert info["dense"]                                       # the fallback reports itself
+    np.testing.assert_allclose(lam, 1.0, rtol=0, atol=1e-8)
+    np.testing.assert_allclose(V.T @ V, np.eye(K), rtol=0, atol=1e-12)
+    assert np.abs(G @ V - V * lam).max() < 1e-9
+    # the whole path with r = 1: runs, and H = U e^{-t(1-1)} U^T restricted to K columns is a projector-like PSD block
+    X, U0, U = make_case(2000, 3, 100, 1, seed=5)
+    H = api.heat_kernel_covariance_cpp(X[:50], X[50:], 100, 1, 1.0, 10, dict(kernel="lae", gl="normalized", root=True), 1, 0.1, U=U)
+    assert H.shape == (2000, 50) and np.isfinite(H).all()
+    assert np.linalg.eigvalsh(0.5 * (H[:50] + H[:50].T)).min() > -1e-9
+
+
 def test_eig_blocksparse_matches_dense(stages):
     """The Gram matrix of a neighbourhood graph is sparse; from s = 3072 on the solver permutes it and multiplies
     only the populated 16 x 128 blocks (+ a CSR remainder).  That must not change the result beyond rounding:
