@@ -1180,7 +1180,7 @@ static size_t eig_workspace_bytes(int s, int K) {
   tot += 4 * align_up(sizeof(double) * (size_t)b);
   tot += align_up(sizeof(int) * (size_t)b) + align_up(sizeof(int) * 16);
   if (!dense) tot += align_up(sizeof(double) * eig_gemm_ws_elems(s, b));
-  if (!dense && s >= 1024) tot += bs_workspace_bytes(s, b);   // (used from s = 3072 on by default; tunable)
+  if (!dense && s >= 1024) tot += bs_workspace_bytes(s, b);   // (used from s = 1536 on by default; tunable)
   return tot + 1024;
 }
 
@@ -1356,7 +1356,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   w.gemm_ws_elems = dense ? 0 : eig_gemm_ws_elems(s, b);
   w.gemm_ws = dense ? nullptr : (double *)take(sizeof(double) * w.gemm_ws_elems);
   BlockSparseG bs;
-  if (!dense && s >= std::max(1024, tuning("eig_bs_min_s", 3072)) && tuning("eig_blocksparse", 1)) {
+  if (!dense && s >= std::max(1024, tuning("eig_bs_min_s", 1536)) && tuning("eig_blocksparse", 1)) {
     bs.ntile = (s + 127) / 128; bs.nstage = (s + 15) / 16;
     BsScratch sc;
     bs.Gp = (double *)take(sizeof(double) * (size_t)s * s);

@@ -1,11 +1,13 @@
-"""A few larger random configurations (block-sparse eigensolver range, many GEMM tiles) against the oracle."""
+"""A few larger random configurations (block-sparse eigensolver range, many GEMM tiles) against the oracle:
+python scripts/stress_large.py [seed] [cases] [smin] [smax]"""
 import sys, time, numpy as np
 sys.path.insert(0, ".")
 from flgp_amd import api, synth
 from oracle import flgp_oracle as O
 rng = np.random.default_rng(int(sys.argv[1]) if len(sys.argv) > 1 else 0)
 for c in range(int(sys.argv[2]) if len(sys.argv) > 2 else 4):
-    d = int(rng.choice([3, 8, 16, 24])); s = int(rng.integers(3072, 4600)); n = int(rng.integers(40000, 120000))
+    smin = int(sys.argv[3]) if len(sys.argv) > 3 else 3072; smax = int(sys.argv[4]) if len(sys.argv) > 4 else 4600
+    d = int(rng.choice([3, 8, 16, 24])); s = int(rng.integers(smin, smax)); n = int(rng.integers(40000, 120000))
     r = int(rng.integers(3, 12)); K = int(rng.integers(30, 160)); m = int(rng.integers(50, 600))
     kernel = str(rng.choice(["lae", "se"])); gl = str(rng.choice(["rw", "normalized", "cluster-normalized"])); root = bool(rng.integers(0, 2))
     X = synth.gaussian_mixture(n, d, components=int(rng.integers(4, 30)), seed=int(rng.integers(1, 1 << 30)))
