@@ -1272,7 +1272,7 @@ static int jacobi_refine(hipStream_t st, const double *T, int b, int K, EigWork 
                                  (int)lds_small));
     const double tol_g = 4.0 * std::sqrt((double)g) * 1.1102230246251565e-16;
     hipLaunchKernelGGL(small_sym_eig_kernel<64>, dim3(1), dim3(1024), lds_small, st, T + (size_t)K * b + K, b, g, Vg,
-                       tol_g, tuning("eig_guard_sweeps", 2));
+                       tol_g, tuning("eig_guard_sweeps", 1));
     FLGP_TRY(check_launch("small_sym_eig_kernel"));
   } else {
     // a guard block too large for one workgroup's LDS: the block Jacobi on the g x g matrix itself
@@ -1640,7 +1640,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   // ---- Chebyshev filter on [0, cut], scaled to 1 at the top Ritz value
   struct FilterPlan { double c, e, sigma1; int m; };
   auto plan_filter = [&](double top, int it_) {
-    const int cut_pos = K + (b - K) * tuning("eig_cut_pct", 100) / 100;
+    const int cut_pos = K + (b - K) * tuning("eig_cut_pct", 90) / 100;
     double cut = theta[std::min(b - 1, std::max(K, cut_pos - 1))];
     if (!(cut > 0.0)) cut = 1e-3 * top;
     if (cut > 0.999 * top) cut = 0.999 * top;   // degenerate block: keep a valid interval
@@ -1649,7 +1649,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     const double g1 = (top - fp.c) / fp.e;      // >= 1
     // degree: amplification T_m(g1) of the top direction capped per outer iteration
     // (gentler while the block is still far from the invariant subspace)
-    const double amp = std::pow(10.0, (double)((it_ < 2) ? tuning("eig_amp_exp_early", 3) : tuning("eig_amp_exp", 7)));
+    const double amp = std::pow(10.0, (double)((it_ < 2) ? tuning("eig_amp_exp_early", 3) : tuning("eig_amp_exp", 8)));
     int m = (int)std::floor(std::acosh(amp) / std::acosh(std::max(g1, 1.0 + 1e-12)));
     fp.m = std::max(2, std::min(m, 40));
     fp.sigma1 = fp.e / (top - fp.c);
@@ -1758,7 +1758,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     // rotation W is applied to the filtered block afterwards.  Not on the step that is expected to
     // converge: there the filter's products would be thrown away.
     const bool overlap = can_overlap && do_rr && it >= 3 && !near_done &&
-                         rmax_prev <= 1e-6 * (double)tuning("eig_overlap_below_e6", 1000);
+                         rmax_prev <= 1e-6 * (double)tuning("eig_overlap_below_e6", 10000);
     double rmax = rmax_prev * rate, top = std::max(theta[0], 1e-300);
     if (do_rr && overlap) {
       since_rr = 0;
