@@ -1611,14 +1611,19 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     return rotate(Yin, w.W, Qout);
   };
 
-  // ---- start block, orthonormalised twice.  Four s x b buffers rotate through the roles
+  // ---- start block, orthonormalised (uniform random: condition ~ (sqrt s + sqrt b) / (sqrt s - sqrt b), and orth()
+  //      iterates to convergence by itself, so once is enough).  Four s x b buffers rotate through the roles
   //      Q (orthonormal block) and three free ones.
   double *Q = w.Q, *F[3] = {w.Y, w.Yp, w.Z};
   hipLaunchKernelGGL(eig_init_q_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, st, F[0], s, b, s);
   FLGP_TRY(check_launch("eig_init_q_kernel"));
   double cond = 0.0;
-  FLGP_TRY(orth(F[0], F[1], &cond));
-  FLGP_TRY(orth(F[1], Q, &cond));
+  if (tuning("eig_start_orths", 1) >= 2) {
+    FLGP_TRY(orth(F[0], F[1], &cond));
+    FLGP_TRY(orth(F[1], Q, &cond));
+  } else {
+    FLGP_TRY(orth(F[0], Q, &cond));
+  }
 
   std::vector<double> theta(b), res(K);
   int gprods = 0, it = 0;
