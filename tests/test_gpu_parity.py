@@ -240,6 +240,17 @@ def test_random_shapes_whole_path(oracle, seed):
         assert err < 1e-7, (err, dict(n=n, d=d, s=s, r=r, m=m, K=K, kernel=kernel, gl=gl, root=root, t=t))
 
 
+def test_run_to_run_bits(oracle):
+    """the same call twice gives the same bits: fixed-order reductions everywhere, including the solver's second
+    stream (scripts/check_determinism.py is the large version)"""
+    X, U0, U = make_case(20000, 8, 1600, 6, seed=12)          # s >= 1536: block-sparse products, overlapped refinement
+    models = dict(kernel="lae", gl="cluster-normalized", root=True)
+    H = [api.heat_kernel_covariance_cpp(X[:100], X[100:], 1600, 6, 2.0, 60, models, 1, 0.1, U=U) for _ in range(2)]
+    np.testing.assert_array_equal(H[0], H[1])
+    ny = [api.nystrom_eigenpair_cpp(X[:3000], U0[:300], 1.0, 20) for _ in range(2)]
+    np.testing.assert_array_equal(ny[0].vectors, ny[1].vectors)
+
+
 def test_cluster_normalized_needs_sizes():
     X, U0, U = make_case(100, 2, 10, 3, seed=1)
     with pytest.raises(api.FlgpError) as e:
