@@ -1,0 +1,63 @@
+// Block-sparse products with the Gram matrix G = A^T A for the eigensolver's Chebyshev filter (bsg.hip).
+//
+// G couples two anchors only if some point has both among its r nearest: 5 % of G is non-zero at BASELINE configs[2]
+// (s = 5000, r = 10, 238 entries per row).  G is the weight matrix of a neighbourhood graph with cluster / manifold
+// structure, so a symmetric permutation concentrates it: after the ordering built here 9 % of the 64 x 16 blocks of
+// P G P^T hold 98.8 % of the non-zeros.  A product then is
+//     (kept blocks: MFMA GEMM over the listed 16-deep k stages of every 64-row tile)  +  (the scattered rest: CSR),
+// on blocks stored transposed (b x s, the b values of one anchor contiguous).  The ordering can only change how much
+// work is skipped, never a result beyond rounding.
+#pragma once
+#include "common.h"
+
+namespace flgp {
+
+constexpr int BSG_TM = 64;        // anchors per output tile
+constexpr int BSG_TN = 64;        // block columns per output tile
+constexpr int BSG_SK = 16;        // k depth of a stage
+constexpr int BSG_SEEDS = 64;     // clusters of the ordering
+constexpr int BSG_META = 16;      // ints of device -> host bookkeeping
+
+struct BsG {
+  bool built = false;             // set-up enqueued; `on` is decided by bsg_finish() once the stream has been synchronised
+  bool on = false;
+  int s = 0, ntile = 0, nstage = 0;
+  // CSR of G in the caller's anchor order
+  int *gptr = nullptr, *gcol = nullptr;
+  double *gval = nullptr;
+  size_t csr_cap = 0;
+  // ordering
+  int *lab = nullptr, *perm = nullptr, *iperm = nullptr;
+  double *E0 = nullptr, *E1 = nullptr, *Cw = nullptr;
+  // kept blocks of P G P^T
+  int *cnt = nullptr, *blkpos = nullptr, *nk = nullptr, *off = nullptr, *klist = nullptr, *order = nullptr;
+  double *pack = nullptr;
+  size_t pack_cap = 0;            // blocks
+  // the scattered rest, rows in permuted order
+  int *rcnt = nullptr, *rptr = nullptr, *rcol = nullptr;
+  double *rval = nullptr;
+  size_t rem_cap = 0;
+  // per-row figures of G gathered while the CSR is counted: absolute column sums, diagonal
+  double *colabs = nullptr, *diag = nullptr, *bounds = nullptr;
+  double h_bounds[2] = {0.0, 0.0};   // 1-norm of G (>= lambda_max), trace of G; valid like h_meta
+  int *meta = nullptr;            // device: see BSG_M_* in bsg.hip
+  int *head = nullptr;            // work-queue heads of the product kernel (ring of 2)
+  double *T[3] = {nullptr, nullptr, nullptr};   // b x s blocks of the transposed filter
+  int h_meta[BSG_META] = {0};     // host copy, valid after the stream has been synchronised
+  int launches = 0;               // products issued (selects the queue head)
+};
+
+size_t bsg_workspace_bytes(int s, int b);
+// carve the members out of a workspace (advances p)
+void bsg_carve(BsG &g, char *&p, int s, int b);
+// Enqueues the whole set-up (one host round trip in the middle, for the 64-cluster chain).  On return the device work
+// is queued and the bookkeeping is on its way to g.h_meta; call bsg_finish() after the next stream synchronisation.
+int bsg_setup(hipStream_t st, const double *dG, int ldg, int s, BsG &g);
+// after a synchronisation: decides g.on (false when G does not concentrate: the caller multiplies with the dense G)
+void bsg_finish(BsG &g);
+// out_t = alpha X_t (P G P^T) + beta E_t + gamma E2_t   (all b x s, b contiguous; E_t / E2_t may be null; out_t must not
+// alias X_t)
+int bsg_product(hipStream_t st, BsG &g, const double *Xt, int b, double alpha, double beta, const double *Et,
+                double gamma, const double *E2t, double *out_t);
+
+}  // namespace flgp

@@ -66,35 +66,19 @@ inline int check_launch(const char *what) {
   return FLGP_OK;
 }
 
-// Optional block-sparse reduction for gemm_launch: per 128-wide tile of one operand (rows of A if on_a, columns
-// of B otherwise; the last tile slid back inside like the kernel's edge tiles) the list of 16-deep k stages that
-// hold any of its nonzeros.  Stages not listed are skipped.
-struct GemmStageList {
-  const int *klist;     // [tiles][ld] stage numbers, ascending
-  const int *nk;        // [tiles] entries per tile
-  int ld;
-  bool on_a;
-  long total_stages;    // sum of nk
-  int max_stages;       // max of nk
-  // optional balanced partition: n_items work items {tile, first entry, end entry, z} (4 ints each) that cut every
-  // tile's list into pieces of similar length; nz[tile] pieces per tile, at most zmax
-  const int *wl;
-  int n_items;
-  const int *nz;
-  int zmax;
-  // optional: the listed blocks of the sparse operand copied out into one contiguous array, block e of tile t
-  // (e = off[t] + position in the tile's list) as 16 rows of 128 values (k-major, zero padded at the edges), so
-  // that a stage is one 16 KB read instead of 16 reads a matrix column apart
-  const double *packed;
-  const int *off;
-};
-
 // C(i,j) = alpha * sum_k A(i,k) B(k,j) + beta * E(i,j) + gamma * E2(i,j)   (gemm.hip)
 int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double *A, long a_is, long a_ks,
                 const double *B, long b_ks, long b_js, double beta, const double *E, long e_is, long e_js,
                 double *C, long c_is, long c_js, double *work, size_t work_elems, double gamma,
-                const double *E2, const GemmStageList *sl = nullptr);
+                const double *E2, int *tickets = nullptr);
+// `tickets`: GEMM_MAX_TICKETS zero-initialised ints owned by the caller (one stream at a time, like `work`); with them
+// a split-K product finishes inside the GEMM kernel (the last piece of a tile to arrive adds the partial planes in a
+// fixed order) instead of in a second launch.  The kernel leaves them zero.
+constexpr int GEMM_MAX_TICKETS = 1024;
 
+
+// host wait for a stream that polls an event instead of sleeping in hipStreamSynchronize (eig.hip)
+hipError_t stream_wait(hipStream_t st);
 
 // Register-resident LAE kernels (lae_reg*.hip).  Returns FLGP_LAE_REG_NONE when no kernel of the family
 // is built for (r, d) and the caller falls through to the LDS kernels of lae.hip.

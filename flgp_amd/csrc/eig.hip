@@ -22,6 +22,7 @@
 // pairs in a round; a launch boundary is the inter-workgroup barrier).  Rotations are
 // accumulated in V explicitly, so V stays orthogonal to rounding even for tiny eigenvalues.
 #include "common.h"
+#include "bsg.h"
 #include <algorithm>
 #include <mutex>
 #include <cmath>
@@ -87,7 +88,7 @@ static hipError_t mark_wait() {
     if (e != hipErrorNotReady) return e;
   }
 }
-static hipError_t stream_wait(hipStream_t st) {
+hipError_t stream_wait(hipStream_t st) {
   if (!g_ctx || !g_ctx->wait_ev || tuning("eig_spin_wait", 1) == 0) return hipStreamSynchronize(st);
   hipError_t e = hipEventRecord(g_ctx->wait_ev, st);
   if (e != hipSuccess) return e;
@@ -726,6 +727,33 @@ __global__ void resid_kernel(const double *__restrict__ Z, const double *__restr
   if (threadIdx.x == 0) res[j] = __builtin_sqrt(red[0]);
 }
 
+// A-priori spectrum bounds of the symmetric PSD matrix G, for the one filter that runs before any Rayleigh-Ritz step:
+// out[blk] = max over the columns of block blk of the absolute column sum (>= lambda_max: the 1-norm), out[nblk + blk] =
+// the block's share of the trace.  One wave per column, APRIORI_BLOCKS workgroups of four waves.
+constexpr int APRIORI_BLOCKS = 256;
+__global__ __launch_bounds__(256) void apriori_bounds_kernel(const double *__restrict__ G, int ldg, int s,
+                                                             double *__restrict__ out) {
+  __shared__ double wmax[4], wtr[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double cmax = 0.0, tr = 0.0;
+  for (int j = blockIdx.x * 4 + wave; j < s; j += APRIORI_BLOCKS * 4) {
+    const double *col = G + (size_t)j * ldg;
+    double a = 0.0;
+    for (int i = lane; i < s; i += 64) a += __builtin_fabs(col[i]);
+    for (int off = 32; off > 0; off >>= 1) a += __shfl_xor(a, off, 64);
+    cmax = a > cmax ? a : cmax;
+    tr += col[j];
+  }
+  if (lane == 0) { wmax[wave] = cmax; wtr[wave] = tr; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double m = wmax[0], t = wtr[0];
+    for (int q = 1; q < 4; ++q) { m = wmax[q] > m ? wmax[q] : m; t += wtr[q]; }
+    out[blockIdx.x] = m;
+    out[APRIORI_BLOCKS + blockIdx.x] = t;
+  }
+}
+
 // ------------------------------------------------------------------------------------------
 // host orchestration
 // ------------------------------------------------------------------------------------------
@@ -765,8 +793,9 @@ struct EigWork {
   double *Q, *Y, *Yp, *Z, *Qold;
   // small (b x b)
   double *T, *JB, *JV, *W, *X2, *Id;
-  double *lam, *scale, *res, *dinv, *gemm_ws;
+  double *lam, *scale, *res, *dinv, *gemm_ws, *apriori;
   int *perm, *flags;
+  int *tickets;         // GEMM_MAX_TICKETS zeroed counters of the in-kernel split-K reduction (main stream only)
   size_t gemm_ws_elems;
 };
 
@@ -787,184 +816,14 @@ static bool eig_use_dense(int s, int K) {
 }
 
 static size_t eig_gemm_ws_elems(int s, int b) {
-  // split-K partials: the s x b products use up to 8 splits, the b x b ones up to 128
-  size_t a = (size_t)16 * s * b, c = (size_t)128 * b * b;
+  // split-K partials (whole 128 x 128 tiles): the s x b products use up to 16 planes, the b x b ones up to 128
+  const size_t sp = (size_t)(s + 127) / 128 * 128, bp = (size_t)(b + 127) / 128 * 128;
+  size_t a = (size_t)16 * sp * bp, c = (size_t)128 * bp * bp;
   return a > c ? a : c;
 }
 
-// ------------------------------------------------------------------------------------------
-// Block-sparse products with G.
-//
-// G = A^T A couples two anchors only if some point has both among its r nearest: at C3 (s = 5000, r = 10)
-// 5 % of G is non-zero, 248 entries per row.  In the order the anchors arrive in that is useless to a tiled
-// GEMM (98 % of the 16 x 128 operand blocks hold something), but G is the weight matrix of a neighbourhood
-// graph with cluster / manifold structure, so a symmetric permutation concentrates it: after the ordering
-// below 10 % of the blocks hold 98 % of the non-zeros (scripts/exp_gorder.py).  The filter's products then
-// run as  (dense blocks: tiled MFMA GEMM over the listed k stages only)  +  (the scattered rest: a small
-// CSR product),  on the permuted matrix P G P^T; the eigenvectors are permuted back at the end.  Nothing
-// here can change a result beyond rounding: the ordering only decides how much work is skipped.
-//
-// Ordering, from G alone (no coordinates): p seed anchors, three hops of diffusion G^3 e_seed (one GEMM per
-// hop), every anchor joins the seed it received most from, two rounds of label smoothing (take the label
-// that carries most weight among the neighbours), then the clusters are chained greedily by their mutual
-// weight so that related clusters sit next to each other.
-// ------------------------------------------------------------------------------------------
-constexpr int BS_SEEDS = 64;     // seed anchors / clusters of the ordering
-constexpr int BS_DENSE = 32;     // a 16 x 128 block with at least this many non-zeros goes to the tiled GEMM
+// Block-sparse products with G: bsg.h / bsg.hip.  The two kernels below move blocks in and out of its transposed layout.
 
-__global__ void bs_seed_kernel(double *__restrict__ E, int s, int p) {
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (long)s * p) return;
-  const int i = (int)(e % s), q = (int)(e / s);
-  E[e] = (i == (int)(((long)q * s) / p)) ? 1.0 : 0.0;
-}
-// label = column of the largest entry in row i (lowest column on ties; p if the row is all zero)
-__global__ void bs_argmax_kernel(const double *__restrict__ E, int s, int p, int *__restrict__ lab) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= s) return;
-  double best = 0.0; int bq = p;
-  for (int q = 0; q < p; ++q) {
-    const double v = E[(size_t)q * s + i];
-    if (v > best) { best = v; bq = q; }
-  }
-  lab[i] = bq;
-}
-__global__ void bs_onehot_kernel(const int *__restrict__ lab, int s, int p, double *__restrict__ OH) {
-  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= (long)s * p) return;
-  const int i = (int)(e % s), q = (int)(e / s);
-  OH[e] = (lab[i] == q) ? 1.0 : 0.0;
-}
-// Gp(i', k') = G(perm[i'], perm[k'])
-// One workgroup per destination column: the source column (s doubles) is then pulled into one XCD's L2 once; split
-// over several workgroups it was fetched by every XCD they landed on (measured: 1.4 GB fetched for a 200 MB matrix).
-__global__ __launch_bounds__(1024) void bs_permute_kernel(const double *__restrict__ G, int ldg, int s,
-                                                          const int *__restrict__ perm, double *__restrict__ Gp) {
-  const int kp = blockIdx.x;
-  const double *src = G + (size_t)perm[kp] * ldg;
-  for (int ip = threadIdx.x; ip < s; ip += 1024) Gp[(size_t)kp * s + ip] = src[perm[ip]];
-}
-// non-zeros of the 16 x 128 block (k stage, i tile) of Gp; Gp(i, k) at i + k*s
-__global__ __launch_bounds__(128) void bs_count_kernel(const double *__restrict__ Gp, int s, int nstage,
-                                                       int *__restrict__ cnt) {
-  const int stage = blockIdx.x, tile = blockIdx.y;
-  const int i = tile * 128 + threadIdx.x;
-  int c = 0;
-  if (i < s) {
-    // read as Gp(i, k) -- the element bs_pack_kernel copies out for the GEMM -- so lanes run along a column:
-    // 128 contiguous doubles per k (the transposed read fetched every line of the block 16 times over)
-    for (int k = 0; k < 16; ++k)
-      if (stage * 16 + k < s && Gp[(size_t)(stage * 16 + k) * s + i] != 0.0) ++c;
-  }
-  __shared__ int red[128];
-  red[threadIdx.x] = c;
-  __syncthreads();
-  for (int off = 64; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) cnt[tile * nstage + stage] = red[0];
-}
-// block e = (tile t, stage g) of the list copied out: pack[e][kk][r] = Gp(t*128 + r, g*16 + kk), zero outside the matrix
-__global__ __launch_bounds__(256) void bs_pack_kernel(const double *__restrict__ Gp, int s, const int *__restrict__ klist,
-                                                      int kl_ld, const int *__restrict__ off, int ntile,
-                                                      double *__restrict__ pack) {
-  const int e = blockIdx.x;
-  int t = 0;
-  while (t + 1 < ntile && off[t + 1] <= e) ++t;      // few tiles: a linear search is fine
-  const int g = klist[(size_t)t * kl_ld + (e - off[t])];
-  for (int x = threadIdx.x; x < 16 * 128; x += 256) {
-    const int kk = x >> 7, r = x & 127;
-    const int i = t * 128 + r, k = g * 16 + kk;
-    pack[(size_t)e * 2048 + x] = (i < s && k < s) ? Gp[(size_t)k * s + i] : 0.0;
-  }
-}
-// the rest: non-zeros of row i that sit in blocks the GEMM skips.  One wave per row, column i of Gp read
-// contiguously (symmetry); count pass (fill == 0) and fill pass (entries in ascending k).
-__global__ __launch_bounds__(64) void bs_remainder_kernel(const double *__restrict__ Gp, int s, int nstage,
-                                                          const unsigned char *__restrict__ dense,
-                                                          const int *__restrict__ rptr, int *__restrict__ rcnt,
-                                                          int *__restrict__ rcol, double *__restrict__ rval, int fill) {
-  const int i = blockIdx.x, lane = threadIdx.x;
-  const unsigned char *dn = dense + (size_t)(i / 128) * nstage;
-  const double *col = Gp + (size_t)i * s;
-  int n = 0;
-  const int base = fill ? rptr[i] : 0;
-  for (int k0 = 0; k0 < s; k0 += 64) {
-    const int k = k0 + lane;
-    const double v = (k < s) ? col[k] : 0.0;
-    const bool take = (k < s) && v != 0.0 && !dn[k >> 4];
-    const unsigned long long m = __ballot(take);
-    if (fill && take) {
-      const int o = base + n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0));
-      rcol[o] = k;
-      rval[o] = v;
-    }
-    n += __builtin_popcountll(m);
-  }
-  if (!fill && lane == 0) rcnt[i] = n;
-}
-// out(c, i) += alpha * sum_e rval[e] * X(c, rcol[e]) for the remainder entries e of row i; X, out are b x s, c
-// contiguous.  One workgroup per row: its four waves split the row's entries (a hub anchor can have a couple of
-// hundred: taken by one wave, that row alone would set the kernel's run time), every lane owns four adjacent
-// columns and keeps eight 32-byte row loads in flight; the four partial sums are added in wave order.
-__global__ __launch_bounds__(256) void bs_spmm_kernel(const int *__restrict__ rptr, const int *__restrict__ rcol,
-                                                      const double *__restrict__ rval, const double *__restrict__ Xt, int s,
-                                                      int b, double alpha, double *__restrict__ out) {
-  __shared__ double part[3][256];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int i = blockIdx.x;
-  const int e0 = rptr[i], e1 = rptr[i + 1];
-  if (e0 == e1) return;     // uniform over the workgroup
-  const int n = e1 - e0;
-  const int q = (n <= 8) ? n : (n + 3) / 4;            // short rows: wave 0 alone
-  const int my0 = e0 + wave * q, my1 = (my0 + q < e1) ? my0 + q : e1;
-  for (int c0 = 0; c0 < b; c0 += 256) {
-    const int c = c0 + 4 * lane;
-    const bool okc = c + 3 < b;            // b is a multiple of 16: a lane's four columns are all in or all out
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    for (int eb = my0; eb < my1; eb += 64) {
-      const int ne = (my1 - eb < 64) ? my1 - eb : 64;
-      const int kc = (lane < ne) ? rcol[eb + lane] : 0;
-      const double vc = (lane < ne) ? rval[eb + lane] : 0.0;
-      for (int j = 0; j < ne; j += 8) {
-        d2v xa[8], xb[8];
-        double vv[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          const int jj = (j + u < ne) ? j + u : j;
-          const int k = __shfl(kc, jj, 64);
-          vv[u] = (j + u < ne) ? __shfl(vc, jj, 64) : 0.0;
-          const d2v *x = (const d2v *)(Xt + (size_t)k * b + (okc ? c : 0));
-          xa[u] = x[0];
-          xb[u] = x[1];
-        }
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-          a0 += vv[u] * xa[u][0]; a1 += vv[u] * xa[u][1]; a2 += vv[u] * xb[u][0]; a3 += vv[u] * xb[u][1];
-        }
-      }
-    }
-    if (n > 8) {
-      if (wave > 0) {
-        part[wave - 1][4 * lane + 0] = a0; part[wave - 1][4 * lane + 1] = a1;
-        part[wave - 1][4 * lane + 2] = a2; part[wave - 1][4 * lane + 3] = a3;
-      }
-      __syncthreads();
-      if (wave == 0) {
-#pragma unroll
-        for (int w = 0; w < 3; ++w) {
-          a0 += part[w][4 * lane + 0]; a1 += part[w][4 * lane + 1]; a2 += part[w][4 * lane + 2]; a3 += part[w][4 * lane + 3];
-        }
-      }
-      __syncthreads();
-    }
-    if (wave == 0 && okc) {
-      double *o = out + (size_t)i * b + c;
-      o[0] += alpha * a0; o[1] += alpha * a1; o[2] += alpha * a2; o[3] += alpha * a3;
-    }
-  }
-}
 // tiled transpose: in is R x C with element (r, c) at r + c*R; out(c, r) at c + r*C
 __global__ void bs_transpose_kernel(const double *__restrict__ in, int R, int C, double *__restrict__ out) {
   __shared__ double t[32][33];
@@ -989,198 +848,16 @@ __global__ void bs_unpermute_kernel(const double *__restrict__ R, int s, int K, 
   V[(size_t)k * ldv + perm[ip]] = R[e];
 }
 
-struct BlockSparseG {
-  bool on = false;
-  double *Gp = nullptr;
-  int *perm = nullptr;
-  int *klist = nullptr, *nk = nullptr;
-  int *wl = nullptr, *nz = nullptr;   // balanced work items for the tiled GEMM
-  double *pack = nullptr;             // the listed blocks, contiguous
-  int *off = nullptr;
-  int n_items = 0, zmax = 1;
-  int ntile = 0, nstage = 0;
-  long total = 0;
-  int maxn = 0;
-  int *rptr = nullptr, *rcol = nullptr;
-  double *rval = nullptr;
-  int rnnz = 0;
-  double *T[3] = {nullptr, nullptr, nullptr};   // b x s blocks of the transposed filter
-  double dense_frac = 1.0;
-};
-
-static size_t bs_workspace_bytes(int s, int b) {
-  const int ntile = (s + 127) / 128, nstage = (s + 15) / 16;
-  size_t tot = align_up(sizeof(double) * (size_t)s * s);                         // Gp
-  tot += 3 * align_up(sizeof(double) * (size_t)s * BS_SEEDS);                     // diffusion blocks
-  tot += align_up(sizeof(double) * (size_t)BS_SEEDS * BS_SEEDS);
-  tot += 2 * align_up(sizeof(int) * (size_t)s);                                   // labels, perm
-  tot += 2 * align_up(sizeof(int) * (size_t)ntile * nstage) + align_up(sizeof(int) * (size_t)ntile);   // counts, klist, nk
-  tot += align_up(sizeof(int) * (size_t)ntile * 16 * 4) + align_up(sizeof(int) * (size_t)ntile);          // work items, nz
-  tot += align_up(sizeof(int) * (size_t)(ntile + 1)) + align_up(sizeof(double) * 2048 * ((size_t)ntile * nstage / 2 + 1));   // packed blocks
-  tot += align_up((size_t)ntile * nstage);                                        // dense flags
-  tot += 2 * align_up(sizeof(int) * (size_t)(s + 1));                             // rptr, rcnt
-  tot += align_up(sizeof(int) * (size_t)ntile * nstage * BS_DENSE) + align_up(sizeof(double) * (size_t)ntile * nstage * BS_DENSE);
-  tot += 3 * align_up(sizeof(double) * (size_t)s * b);                            // transposed blocks
-  return tot;
-}
-
-// Builds the permuted copy, the stage lists and the remainder; leaves bs.on = false when the matrix does
-// not concentrate (then the solver multiplies with the dense G as before).  Synchronises the stream.
-struct BsScratch {
-  double *E0, *E1, *E2, *C;
-  int *lab, *cnt, *rcnt;
-  unsigned char *dense;
-};
-static int bs_setup(hipStream_t st, const double *dG, int ldg, int s, int b, double *gemm_ws, size_t gemm_ws_elems,
-                    BlockSparseG &bs, BsScratch &sc) {
-  const int p = BS_SEEDS;
-  const int ntile = bs.ntile, nstage = bs.nstage;
-  const long sp = (long)s * p;
-  auto hop = [&](const double *in, double *out) {   // out = G in   (s x p)
-    return gemm_launch(st, s, p, s, 1.0, dG, 1, ldg, in, 1, s, 0.0, nullptr, 0, 0, out, 1, s, gemm_ws, gemm_ws_elems, 0.0,
-                       nullptr);
-  };
-  hipLaunchKernelGGL(bs_seed_kernel, dim3(ceil_div(sp, 256)), dim3(256), 0, st, sc.E0, s, p);
-  FLGP_TRY(check_launch("bs_seed_kernel"));
-  FLGP_TRY(hop(sc.E0, sc.E1));
-  FLGP_TRY(hop(sc.E1, sc.E2));
-  FLGP_TRY(hop(sc.E2, sc.E1));
-  hipLaunchKernelGGL(bs_argmax_kernel, dim3(ceil_div(s, 256)), dim3(256), 0, st, sc.E1, s, p, sc.lab);
-  for (int round = 0; round < 2; ++round) {     // label smoothing
-    hipLaunchKernelGGL(bs_onehot_kernel, dim3(ceil_div(sp, 256)), dim3(256), 0, st, sc.lab, s, p, sc.E0);
-    FLGP_TRY(hop(sc.E0, sc.E1));
-    hipLaunchKernelGGL(bs_argmax_kernel, dim3(ceil_div(s, 256)), dim3(256), 0, st, sc.E1, s, p, sc.lab);
-  }
-  // cluster-to-cluster weights C = OH^T G OH
-  hipLaunchKernelGGL(bs_onehot_kernel, dim3(ceil_div(sp, 256)), dim3(256), 0, st, sc.lab, s, p, sc.E0);
-  FLGP_TRY(hop(sc.E0, sc.E1));
-  FLGP_TRY(gemm_launch(st, p, p, s, 1.0, sc.E0, s, 1, sc.E1, 1, s, 0.0, nullptr, 0, 0, sc.C, 1, p, gemm_ws, gemm_ws_elems, 0.0,
-                       nullptr));
-  FLGP_TRY(check_launch("bs ordering"));
-  std::vector<int> lab(s);
-  std::vector<double> C((size_t)p * p);
-  FLGP_HIP(hipMemcpyAsync(lab.data(), sc.lab, sizeof(int) * s, hipMemcpyDeviceToHost, st));
-  FLGP_HIP(hipMemcpyAsync(C.data(), sc.C, sizeof(double) * p * p, hipMemcpyDeviceToHost, st));
-  FLGP_HIP(stream_wait(st));
-  // chain the clusters: start at the heaviest, always continue with the unused cluster most strongly tied to the last
-  std::vector<int> order, rank(p + 1, p);
-  std::vector<char> used(p, 0);
-  {
-    int start = 0; double best = -1.0;
-    for (int q = 0; q < p; ++q) {
-      double w = 0.0;
-      for (int q2 = 0; q2 < p; ++q2) if (q2 != q) w += std::fabs(C[(size_t)q2 * p + q]);
-      if (w > best) { best = w; start = q; }
-    }
-    order.push_back(start); used[start] = 1;
-    while ((int)order.size() < p) {
-      const int cur = order.back();
-      int nxt = -1; double bw = -1.0;
-      for (int q = 0; q < p; ++q)
-        if (!used[q] && std::fabs(C[(size_t)q * p + cur]) > bw) { bw = std::fabs(C[(size_t)q * p + cur]); nxt = q; }
-      order.push_back(nxt); used[nxt] = 1;
-    }
-    for (int q = 0; q < p; ++q) rank[order[q]] = q;   // label p (isolated anchors) keeps rank p: last
-  }
-  std::vector<int> perm(s), start(p + 2, 0);
-  for (int i = 0; i < s; ++i) ++start[rank[lab[i]] + 1];
-  for (int q = 0; q <= p; ++q) start[q + 1] += start[q];
-  for (int i = 0; i < s; ++i) perm[start[rank[lab[i]]]++] = i;   // stable counting sort by cluster rank
-  FLGP_HIP(hipMemcpyAsync(bs.perm, perm.data(), sizeof(int) * s, hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(bs_permute_kernel, dim3(s), dim3(1024), 0, st, dG, ldg, s, bs.perm, bs.Gp);
-  hipLaunchKernelGGL(bs_count_kernel, dim3(nstage, ntile), dim3(128), 0, st, bs.Gp, s, nstage, sc.cnt);
-  FLGP_TRY(check_launch("bs_count_kernel"));
-  std::vector<int> cnt((size_t)ntile * nstage);
-  FLGP_HIP(hipMemcpyAsync(cnt.data(), sc.cnt, sizeof(int) * cnt.size(), hipMemcpyDeviceToHost, st));
-  FLGP_HIP(stream_wait(st));   // also keeps `perm` alive until its copy is done
-  std::vector<int> klist((size_t)ntile * nstage), nk(ntile, 0);
-  std::vector<unsigned char> dense((size_t)ntile * nstage, 0);
-  long total = 0, nblocks = 0, rem_bound = 0;
-  int maxn = 0;
-  for (int t = 0; t < ntile; ++t) {
-    for (int g = 0; g < nstage; ++g) {
-      const int c = cnt[(size_t)t * nstage + g];
-      ++nblocks;
-      if (c >= BS_DENSE) { klist[(size_t)t * nstage + nk[t]++] = g; dense[(size_t)t * nstage + g] = 1; }
-      else rem_bound += c;
-    }
-    total += nk[t];
-    maxn = std::max(maxn, nk[t]);
-  }
-  bs.total = total; bs.maxn = maxn;
-  bs.dense_frac = (double)total / (double)nblocks;
-  if (tuning("eig_verbose", 0))
-    fprintf(stderr, "[flgp eig] block-sparse G: %.1f %% of the 16x128 blocks kept for the tiled GEMM (max %d of %d stages per tile), %ld scattered non-zeros\n",
-            100.0 * bs.dense_frac, maxn, nstage, rem_bound);
-  if (bs.dense_frac > 0.01 * std::min(50, tuning("eig_bs_max_pct", 50))) { bs.on = false; return FLGP_OK; }
-  // pieces of similar length: a tile with a long list is cut into more of them (at most 16 partial planes)
-  std::vector<int> wl, nz(ntile, 1);
-  {
-    // one workgroup per CU (or a whole number of them): 276 blocks on 256 CUs take as long as 512 would
-    // (measured: the CUs that get two set the run time), so the piece length is the smallest that keeps
-    // pieces x column tiles within the target
-    const int n_other = (b + 127) / 128;
-    const int target = std::max(1, tuning("eig_bs_wgs", 256) / n_other);
-    int chunk = std::max(1, (int)((total + target - 1) / target));
-    auto count_items = [&](int ch) { long c = 0; for (int t = 0; t < ntile; ++t) c += std::max(1, (nk[t] + ch - 1) / ch); return c; };
-    while (count_items(chunk) > target && chunk < maxn) ++chunk;
-    chunk = std::max(chunk, (maxn + 15) / 16);
-    if (tuning("eig_bs_chunk", 0) > 0) chunk = std::max(tuning("eig_bs_chunk", 0), (maxn + 15) / 16);
-    int zmax = 1;
-    for (int t = 0; t < ntile; ++t) {
-      const int pieces = std::max(1, (nk[t] + chunk - 1) / chunk);
-      nz[t] = pieces; zmax = std::max(zmax, pieces);
-      for (int z = 0; z < pieces; ++z) {
-        wl.push_back(t); wl.push_back((int)((long)z * nk[t] / pieces)); wl.push_back((int)((long)(z + 1) * nk[t] / pieces));
-        wl.push_back(z);
-      }
-    }
-    bs.n_items = (int)wl.size() / 4; bs.zmax = zmax;
-  }
-  std::vector<int> off(ntile + 1, 0);
-  for (int t = 0; t < ntile; ++t) off[t + 1] = off[t] + nk[t];
-  FLGP_HIP(hipMemcpyAsync(bs.off, off.data(), sizeof(int) * (ntile + 1), hipMemcpyHostToDevice, st));
-  FLGP_HIP(hipMemcpyAsync(bs.wl, wl.data(), sizeof(int) * wl.size(), hipMemcpyHostToDevice, st));
-  FLGP_HIP(hipMemcpyAsync(bs.nz, nz.data(), sizeof(int) * ntile, hipMemcpyHostToDevice, st));
-  FLGP_HIP(hipMemcpyAsync(bs.klist, klist.data(), sizeof(int) * klist.size(), hipMemcpyHostToDevice, st));
-  FLGP_HIP(hipMemcpyAsync(bs.nk, nk.data(), sizeof(int) * ntile, hipMemcpyHostToDevice, st));
-  FLGP_HIP(hipMemcpyAsync(sc.dense, dense.data(), dense.size(), hipMemcpyHostToDevice, st));
-  if (total > 0) {
-    hipLaunchKernelGGL(bs_pack_kernel, dim3((unsigned)total), dim3(256), 0, st, bs.Gp, s, bs.klist, nstage, bs.off, ntile, bs.pack);
-    FLGP_TRY(check_launch("bs_pack_kernel"));
-  }
-  hipLaunchKernelGGL(bs_remainder_kernel, dim3(s), dim3(64), 0, st, bs.Gp, s, nstage, sc.dense, nullptr, sc.rcnt, nullptr,
-                     nullptr, 0);
-  FLGP_TRY(check_launch("bs_remainder_kernel"));
-  std::vector<int> rcnt(s), rptr(s + 1, 0);
-  FLGP_HIP(hipMemcpyAsync(rcnt.data(), sc.rcnt, sizeof(int) * s, hipMemcpyDeviceToHost, st));
-  FLGP_HIP(stream_wait(st));
-  for (int i = 0; i < s; ++i) rptr[i + 1] = rptr[i] + rcnt[i];
-  bs.rnnz = rptr[s];
-  if (tuning("eig_verbose", 0)) {
-    int mx = 0, over64 = 0;
-    for (int i = 0; i < s; ++i) { mx = std::max(mx, rcnt[i]); over64 += rcnt[i] > 64; }
-    fprintf(stderr, "[flgp eig] remainder: %d entries, longest row %d, rows over 64: %d\n", bs.rnnz, mx, over64);
-  }
-  FLGP_HIP(hipMemcpyAsync(bs.rptr, rptr.data(), sizeof(int) * (s + 1), hipMemcpyHostToDevice, st));
-  hipLaunchKernelGGL(bs_remainder_kernel, dim3(s), dim3(64), 0, st, bs.Gp, s, nstage, sc.dense, bs.rptr, sc.rcnt, bs.rcol,
-                     bs.rval, 1);
-  FLGP_TRY(check_launch("bs_remainder_kernel"));
-  FLGP_HIP(stream_wait(st));
-  bs.on = true;
-  return FLGP_OK;
-}
-
 static size_t eig_workspace_bytes(int s, int K) {
   const bool dense = eig_use_dense(s, K);
   const int b = dense ? s : eig_block_size(s, K);
   size_t tot = 0;
   if (!dense) tot += 5 * align_up(sizeof(double) * (size_t)s * b);
   tot += 6 * align_up(sizeof(double) * (size_t)b * b);
-  tot += 4 * align_up(sizeof(double) * (size_t)b);
-  tot += align_up(sizeof(int) * (size_t)b) + align_up(sizeof(int) * 16);
+  tot += 4 * align_up(sizeof(double) * (size_t)b) + align_up(sizeof(double) * 2 * APRIORI_BLOCKS);
+  tot += align_up(sizeof(int) * (size_t)b) + align_up(sizeof(int) * 16) + align_up(sizeof(int) * GEMM_MAX_TICKETS);
   if (!dense) tot += align_up(sizeof(double) * eig_gemm_ws_elems(s, b));
-  if (!dense && s >= 1024) tot += bs_workspace_bytes(s, b);   // (used from s = 1536 on by default; tunable)
+  if (!dense && s >= 1024) tot += bsg_workspace_bytes(s, b);   // (used from s = 1536 on by default; tunable)
   return tot + 1024;
 }
 
@@ -1352,35 +1029,16 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   w.X2 = (double *)take(small); w.Id = (double *)take(small);
   w.lam = (double *)take(sizeof(double) * b); w.scale = (double *)take(sizeof(double) * b);
   w.res = (double *)take(sizeof(double) * b); w.dinv = (double *)take(sizeof(double) * b);
+  w.apriori = (double *)take(sizeof(double) * 2 * APRIORI_BLOCKS);
   w.perm = (int *)take(sizeof(int) * b); w.flags = (int *)take(sizeof(int) * 16);
+  w.tickets = (int *)take(sizeof(int) * GEMM_MAX_TICKETS);
+  FLGP_HIP(hipMemsetAsync(w.tickets, 0, sizeof(int) * GEMM_MAX_TICKETS, st));
   w.gemm_ws_elems = dense ? 0 : eig_gemm_ws_elems(s, b);
   w.gemm_ws = dense ? nullptr : (double *)take(sizeof(double) * w.gemm_ws_elems);
-  BlockSparseG bs;
+  BsG bs;
   if (!dense && s >= std::max(1024, tuning("eig_bs_min_s", 1536)) && tuning("eig_blocksparse", 1)) {
-    bs.ntile = (s + 127) / 128; bs.nstage = (s + 15) / 16;
-    BsScratch sc;
-    bs.Gp = (double *)take(sizeof(double) * (size_t)s * s);
-    sc.E0 = (double *)take(sizeof(double) * (size_t)s * BS_SEEDS);
-    sc.E1 = (double *)take(sizeof(double) * (size_t)s * BS_SEEDS);
-    sc.E2 = (double *)take(sizeof(double) * (size_t)s * BS_SEEDS);
-    sc.C = (double *)take(sizeof(double) * (size_t)BS_SEEDS * BS_SEEDS);
-    sc.lab = (int *)take(sizeof(int) * (size_t)s);
-    bs.perm = (int *)take(sizeof(int) * (size_t)s);
-    sc.cnt = (int *)take(sizeof(int) * (size_t)bs.ntile * bs.nstage);
-    bs.klist = (int *)take(sizeof(int) * (size_t)bs.ntile * bs.nstage);
-    bs.nk = (int *)take(sizeof(int) * (size_t)bs.ntile);
-    bs.wl = (int *)take(sizeof(int) * (size_t)bs.ntile * 16 * 4);
-    bs.nz = (int *)take(sizeof(int) * (size_t)bs.ntile);
-    bs.off = (int *)take(sizeof(int) * (size_t)(bs.ntile + 1));
-    // packed blocks: the block-sparse path is only taken below eig_bs_max_pct (50 %) of all blocks
-    bs.pack = (double *)take(sizeof(double) * 2048 * ((size_t)bs.ntile * bs.nstage / 2 + 1));
-    sc.dense = (unsigned char *)take((size_t)bs.ntile * bs.nstage);
-    bs.rptr = (int *)take(sizeof(int) * (size_t)(s + 1));
-    sc.rcnt = (int *)take(sizeof(int) * (size_t)(s + 1));
-    bs.rcol = (int *)take(sizeof(int) * (size_t)bs.ntile * bs.nstage * BS_DENSE);
-    bs.rval = (double *)take(sizeof(double) * (size_t)bs.ntile * bs.nstage * BS_DENSE);
-    for (int q = 0; q < 3; ++q) bs.T[q] = (double *)take(sizeof(double) * (size_t)s * b);
-    FLGP_TRY(bs_setup(st, dG, ldg, s, b, w.gemm_ws, w.gemm_ws_elems, bs, sc));
+    bsg_carve(bs, p, s, b);
+    FLGP_TRY(bsg_setup(st, dG, ldg, s, bs));
   }
 
   std::vector<double> lam;
@@ -1406,7 +1064,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   auto gemmG = [&](const double *Xin, double alpha, double beta, const double *E, double gamma, const double *E2,
                    double *out) {  // out = alpha G Xin + beta E + gamma E2   (s x b)
     return gemm_launch(st, s, b, s, alpha, dG, 1, ldg, Xin, 1, s, beta, E, 1, s, out, 1, s, w.gemm_ws,
-                       w.gemm_ws_elems, gamma, E2);
+                       w.gemm_ws_elems, gamma, E2, w.tickets);
   };
   // ---- block-sparse products (bs.on): blocks live transposed (b x s, the b values of one row contiguous) while
   //      the filter runs, so that both the tiled GEMM (over the listed k stages of P G P^T) and the CSR remainder
@@ -1421,23 +1079,16 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   };
   auto gemmG_t = [&](const double *Xt, double alpha, double beta, const double *Et, double gamma, const double *E2t,
                      double *out_t) -> int {   // out_t = alpha X_t G' + beta E_t + gamma E2_t   (b x s)
-    GemmStageList sl{bs.klist, bs.nk, bs.nstage, false, bs.total, bs.maxn, bs.wl, bs.n_items, bs.nz, bs.zmax, bs.pack, bs.off};
-    FLGP_TRY(gemm_launch(st, b, s, s, alpha, Xt, 1, b, bs.Gp, s, 1, beta, Et, 1, b, out_t, 1, b, w.gemm_ws, w.gemm_ws_elems,
-                         gamma, E2t, &sl));
-    if (bs.rnnz > 0) {
-      hipLaunchKernelGGL(bs_spmm_kernel, dim3(s), dim3(256), 0, st, bs.rptr, bs.rcol, bs.rval, Xt, s, b, alpha, out_t);
-      FLGP_TRY(check_launch("bs_spmm_kernel"));
-    }
-    return FLGP_OK;
+    return bsg_product(st, bs, Xt, b, alpha, beta, Et, gamma, E2t, out_t);
   };
   const double *t_q = nullptr, *t_z = nullptr;   // blocks whose transposes currently sit in bs.T[0], bs.T[1]
   auto gram_small = [&](const double *Xa, const double *Xb, double *out) {  // out = Xa^T Xb   (b x b)
     return gemm_launch(st, b, b, s, 1.0, Xa, s, 1, Xb, 1, s, 0.0, nullptr, 0, 0, out, 1, b, w.gemm_ws,
-                       w.gemm_ws_elems, 0.0, nullptr);
+                       w.gemm_ws_elems, 0.0, nullptr, w.tickets);
   };
   auto rotate = [&](const double *Xin, const double *Wm, double *out) {  // out = Xin Wm   (s x b)(b x b)
     return gemm_launch(st, s, b, b, 1.0, Xin, 1, s, Wm, 1, b, 0.0, nullptr, 0, 0, out, 1, s, w.gemm_ws,
-                       w.gemm_ws_elems, 0.0, nullptr);
+                       w.gemm_ws_elems, 0.0, nullptr, w.tickets);
   };
   // orthonormalise the columns of Yin into Qout ("SVQB" on the column-normalised block, so that
   // the widely different column norms a Chebyshev filter leaves behind do not enter the
@@ -1617,6 +1268,17 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   double *Q = w.Q, *F[3] = {w.Y, w.Yp, w.Z};
   hipLaunchKernelGGL(eig_init_q_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, st, F[0], s, b, s);
   FLGP_TRY(check_launch("eig_init_q_kernel"));
+  // Rayleigh-Ritz on the random start block yields nothing but bounds, and poor ones (every Ritz value of a random
+  // subspace sits near the mean eigenvalue); the span p(G) Q does not depend on the basis.  So the first filter runs
+  // straight on the start block with a-priori bounds -- damped interval [0, trace / s], scaled at the 1-norm -- and the
+  // first Rayleigh-Ritz step (two Jacobi sweeps, two rotations, a host round trip) is saved.
+  const bool skip_rr0 = tuning("eig_skip_rr0", 1) != 0;
+  double h_apriori[2 * APRIORI_BLOCKS];
+  if (skip_rr0 && !bs.built) {
+    hipLaunchKernelGGL(apriori_bounds_kernel, dim3(APRIORI_BLOCKS), dim3(256), 0, st, dG, ldg, s, w.apriori);
+    FLGP_TRY(check_launch("apriori_bounds_kernel"));
+    FLGP_HIP(hipMemcpyAsync(h_apriori, w.apriori, sizeof(double) * 2 * APRIORI_BLOCKS, hipMemcpyDeviceToHost, st));
+  }
   double cond = 0.0;
   if (tuning("eig_start_orths", 1) >= 2) {
     FLGP_TRY(orth(F[0], F[1], &cond));
@@ -1754,7 +1416,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     // (rmax_prev is then advanced by the measured per-iteration contraction `rate`, so that the Rayleigh-
     //  Ritz step and its convergence test land on the iteration where the tolerance is expected to be met)
     const bool near_done = rmax_prev * rate <= 4.0 * tol;
-    const bool early_skip = tuning("eig_skip_it1", 0) && it == 1;
+    const bool early_skip = (tuning("eig_skip_it1", 0) && it == 1) || (skip_rr0 && it == 0);
     const bool do_rr = !early_skip && !(rr_every > 1 && it >= 3 && rmax_prev < 1e-6 * tuning("eig_rr_skip_below_e6", 1000) && since_rr + 1 < rr_every && !near_done);
     // Late Rayleigh-Ritz steps only refine a nearly diagonal T: the filter does not wait for them.  It is
     // linear, p(G) (Q W) = (p(G) Q) W, so it runs on the block as it is, with the bounds of the previous
@@ -1821,9 +1483,24 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
       } else {
         ++since_rr;
         A = Q; B = Z; free1 = F[1]; free2 = F[2];
-        rmax_prev *= rate;
+        if (it > 0) rmax_prev *= rate;
       }
-      const FilterPlan fp = plan_filter(top, it);
+      FilterPlan fp;
+      if (it == 0 && skip_rr0) {   // (the start orthonormalisation has synchronised the stream: h_apriori is valid)
+        double n1 = 0.0, tr = 0.0;
+        if (bs.built) { n1 = bs.h_bounds[0]; tr = bs.h_bounds[1]; }   // gathered by the block-sparse set-up's pass over G
+        else for (int q = 0; q < APRIORI_BLOCKS; ++q) { n1 = std::max(n1, h_apriori[q]); tr += h_apriori[APRIORI_BLOCKS + q]; }
+        double cut0 = tr / (double)s;
+        if (!(n1 > 0.0) || !std::isfinite(n1)) { set_error("eigensolver: the matrix is zero or not finite"); return FLGP_ERR_INVALID; }
+        if (!(cut0 > 1e-3 * n1)) cut0 = 1e-3 * n1;
+        if (cut0 > 0.5 * n1) cut0 = 0.5 * n1;
+        fp.c = fp.e = 0.5 * cut0;
+        fp.sigma1 = fp.e / (n1 - fp.c);
+        fp.m = std::max(2, tuning("eig_m0", 5));
+        top = n1;
+      } else {
+        fp = plan_filter(top, it);
+      }
       // the Ritz vectors are needed again after the filter (see below): keep a copy
       FLGP_HIP(hipMemcpyAsync(w.Qold, A, sizeof(double) * (size_t)tot, hipMemcpyDeviceToDevice, st));
       FLGP_TRY(apply_filter(fp, A, B, free1, free2, &cur, &spare));
@@ -1834,11 +1511,15 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     //          y_j <- y_j - sum_{i<j} q_i (q_i . y_j)
     //      (two GEMMs).  What is left is nearly orthogonal, so the symmetric orthonormalisation below
     //      no longer mixes eigen-directions and the next T stays diagonal up to the guard block.
-    FLGP_TRY(gram_small(w.Qold, cur, w.T));
-    hipLaunchKernelGGL(mask_strict_upper_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, w.T, b);
-    FLGP_TRY(check_launch("mask_strict_upper_kernel"));
-    FLGP_TRY(gemm_launch(st, s, b, b, -1.0, w.Qold, 1, s, w.T, 1, b, 1.0, cur, 1, s, cur, 1, s, w.gemm_ws, w.gemm_ws_elems,
-                         0.0, nullptr));
+    //      (Not after the a-priori filter of iteration 0: the start block is no Ritz basis, and projecting along its
+    //      columns would take the block out of span p(G) Q.)
+    if (!(it == 0 && skip_rr0)) {
+      FLGP_TRY(gram_small(w.Qold, cur, w.T));
+      hipLaunchKernelGGL(mask_strict_upper_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, w.T, b);
+      FLGP_TRY(check_launch("mask_strict_upper_kernel"));
+      FLGP_TRY(gemm_launch(st, s, b, b, -1.0, w.Qold, 1, s, w.T, 1, b, 1.0, cur, 1, s, cur, 1, s, w.gemm_ws, w.gemm_ws_elems,
+                           0.0, nullptr, w.tickets));
+    }
     // ---- orthonormalise the filtered block (B is free by now; twice if ill-conditioned)
     FLGP_TRY(orth(cur, B, &cond));
     double *R = B;

@@ -43,16 +43,19 @@ struct GemmArgs {
   int shift_edges;                    // edge tiles slide back inside the matrix (they recompute a few columns / rows)
   int ksplit_len;                     // k range per blockIdx.z (multiple of GK); partials when gridDim.z > 1
   double *part;                       // [z][M][N] row-major partials
-  // block-sparse reduction (optional): only the k stages listed for this tile are multiplied.  klist holds, per
-  // tile of the sparse operand (row tiles when klist_on_rows, else column tiles), nk[tile] stage numbers
-  // (k0 = stage * GK) at klist[tile * klist_ld ...]; the gridDim.z blocks of a tile share its list evenly.
-  const int *klist, *nk;
-  int klist_ld, klist_on_rows;
-  const int *wl, *nz;                 // balanced work items (see GemmStageList); gridDim.x = items x tiles of the other side
-  int n_other, zmax;
-  const double *packed;               // listed blocks of the row operand, contiguous (see GemmStageList)
-  const int *off;
+  // in-kernel split-K reduction (optional): one counter per output tile, all zero between launches.  The pieces of a
+  // tile store their accumulators as planes of PLANE doubles in the thread order they are held in, take a ticket, and
+  // the piece that arrives last adds the planes in ascending z (a fixed order: deterministic) and runs the epilogue.
+  int *tickets;
 };
+
+constexpr int PLANE = GB * GB;    // doubles per partial plane of one 128 x 128 tile
+
+// 16-byte store that is written through to the memory side (sc1), so that a workgroup on another XCD can read it
+// after the ticket hand-off without a release fence over this XCD's whole L2 (MI355X guide: "publish-large")
+__device__ __forceinline__ void store_wt_d2(double *p, d2 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" : : "v"(p), "v"(v) : "memory");
+}
 
 // ---- operand staging: a 128(rows) x 16(k) tile goes global -> 8 registers per thread -> LDS [k][row].
 // Three thread mappings, chosen per operand and per stage (uniform over the workgroup):
@@ -213,13 +216,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   // share the long operand's panel through L2 and the short operand stays L2 resident
   int tm = (ntm <= ntn) ? bid % ntm : bid / ntn;
   int tn = (ntm <= ntn) ? bid / ntm : bid % ntn;
-  int zidx = blockIdx.z, wl_s0 = 0, wl_s1 = 0;
-  if (g.wl) {   // balanced block-sparse partition: this block's piece of one tile's stage list
-    const int item = blockIdx.x / g.n_other, other = blockIdx.x % g.n_other;
-    const int4 it = ((const int4 *)g.wl)[item];
-    if (g.klist_on_rows) { tm = it.x; tn = other; } else { tn = it.x; tm = other; }
-    wl_s0 = it.y; wl_s1 = it.z; zidx = it.w;
-  }
+  const int zidx = blockIdx.z;
   int row0 = tm * GB, col0 = tn * GB;
   // An edge tile would stage its operands through the predicated path for all of its k range and, being
   // the slowest block, set the run time (measured: 286 us at 4992, 351 us at 5000).  Where it is safe the
@@ -230,44 +227,16 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     if (col0 + GB > g.N && g.N >= GB) col0 = g.N - GB;
   }
 
-  // the k stages of this block: a contiguous range (dense), or its share of the tile's stage list (block-sparse)
-  int kbeg = 0, kend = g.Kd, ns;
-  const int *kl = nullptr;
-  const double *pk = nullptr;   // this thread's pointer into the packed blocks of the row operand (stage 0 of its piece)
-  if (g.klist) {
-    const int t = g.klist_on_rows ? tm : tn;
-    const int L = g.nk[t];
-    int s0 = (int)((long)blockIdx.z * L / gridDim.z), s1 = (int)((long)(blockIdx.z + 1) * L / gridDim.z);
-    if (g.wl) { s0 = wl_s0; s1 = wl_s1; }
-    kl = g.klist + (size_t)t * g.klist_ld + s0;
-    ns = s1 - s0;
-    if (g.packed) pk = g.packed + ((size_t)g.off[t] + s0) * (GK * GB) + 2 * (tid & 63) + (tid >> 6) * GB;
-  } else {
-    kbeg = blockIdx.z * g.ksplit_len;
-    kend = kbeg + g.ksplit_len;
-    if (kend > g.Kd) kend = g.Kd;
-    ns = (kend - kbeg + GK - 1) / GK;
-    if (ns < 0) ns = 0;
-  }
-  auto kof = [&](int si) { return kl ? kl[si] * GK : kbeg + si * GK; };
-  // operand A of stage si: from the packed blocks when there are any (always a full, in-range 16 x 128 block)
-  auto load_a = [&](double (&reg)[8], const Operand &o, int si, int k0, bool full) {
-    if (pk) {
-      const double *p = pk + (size_t)si * (GK * GB);
-#pragma unroll
-      for (int rep = 0; rep < 4; ++rep) {
-        const d2 v = *(const d2 *)(p + (4 * rep) * GB);
-        reg[2 * rep] = v[0];
-        reg[2 * rep + 1] = v[1];
-      }
-    } else {
-      stage_load(reg, o, k0, kend, full, tid);
-    }
-  };
+  // the k stages of this block: a contiguous range
+  int kbeg = blockIdx.z * g.ksplit_len, kend = kbeg + g.ksplit_len;
+  if (kend > g.Kd) kend = g.Kd;
+  int ns = (kend - kbeg + GK - 1) / GK;
+  if (ns < 0) ns = 0;
+  auto kof = [&](int si) { return kbeg + si * GK; };
+  auto load_a = [&](double (&reg)[8], const Operand &o, int si, int k0, bool full) { stage_load(reg, o, k0, kend, full, tid); };
 
-  Operand oa = make_operand(g.A, g.a_is, g.a_ks, row0, g.M, tid);
+  const Operand oa = make_operand(g.A, g.a_is, g.a_ks, row0, g.M, tid);
   const Operand ob = make_operand(g.B, g.b_js, g.b_ks, col0, g.N, tid);
-  if (pk) oa.mode = LOAD_RC;   // packed blocks use the row-contiguous thread mapping, edge tiles included
   d4 acc[4][4];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi)
@@ -280,7 +249,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     const bool f0 = k0 + GK <= kend;
     load_a(ra, oa, 0, k0, f0);
     stage_load(rb, ob, k0, kend, f0, tid);
-    stage_store(ra, As2[0], oa, f0 || pk, tid);
+    stage_store(ra, As2[0], oa, f0, tid);
     stage_store(rb, Bs2[0], ob, f0, tid);
     if (ns > 1) {
       const int k1 = kof(1);
@@ -297,7 +266,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
     const double *As = As2[cur], *Bs = Bs2[cur];
     if (si + 1 < ns) {      // stage s+1 goes into the other buffer (last read before the previous barrier)
       const bool f1 = kof(si + 1) + GK <= kend;
-      stage_store(ra, As2[cur ^ 1], oa, f1 || pk, tid);
+      stage_store(ra, As2[cur ^ 1], oa, f1, tid);
       stage_store(rb, Bs2[cur ^ 1], ob, f1, tid);
       if (si + 2 < ns) {  // and stage s+2 starts its way from HBM / L2
         const int k2 = kof(si + 2);
@@ -323,7 +292,64 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   }
 
   // epilogue: D(row = (lane>>4) + 4*reg, col = lane&15) of each 16x16 tile
-  const bool partial = gridDim.z > 1 || (g.wl && g.zmax > 1);
+  const bool partial = gridDim.z > 1;
+  if (partial && g.tickets) {
+    // ---- split-K finished inside the kernel
+    __shared__ int last_piece;
+    const int tile_id = tm * ntn + tn;
+    const int npieces = (int)gridDim.z;
+    if (npieces > 1) {
+      double *plane = g.part + ((size_t)zidx * nt + tile_id) * PLANE;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+            store_wt_d2(plane + ((size_t)((mi * 4 + ni) * 2 + h) * 256 + tid) * 2, d2{acc[mi][ni][2 * h], acc[mi][ni][2 * h + 1]});
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) {
+        const int old = __hip_atomic_fetch_add(&g.tickets[tile_id], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last_piece = (old == npieces - 1);
+        if (old == npieces - 1) {
+          __hip_atomic_store(&g.tickets[tile_id], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+      }
+      __syncthreads();
+      if (!last_piece) return;
+      const double *p0 = g.part + (size_t)tile_id * PLANE + (size_t)tid * 2;
+      const size_t zstride = (size_t)nt * PLANE;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        d2 sum[4][2];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) sum[ni][h] = d2{0.0, 0.0};
+        for (int z = 0; z < npieces; ++z) {   // ascending z: the order does not depend on which piece came last
+          d2 v[4][2];
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+              v[ni][h] = __builtin_nontemporal_load((const d2 *)(p0 + z * zstride + (size_t)((mi * 4 + ni) * 2 + h) * 512));
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) sum[ni][h] += v[ni][h];
+        }
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          acc[mi][ni][0] = sum[ni][0][0]; acc[mi][ni][1] = sum[ni][0][1];
+          acc[mi][ni][2] = sum[ni][1][0]; acc[mi][ni][3] = sum[ni][1][1];
+        }
+      }
+    }
+  }
+  const bool to_planes = partial && !g.tickets;
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
@@ -334,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         const int i = row0 + wr + mi * 16 + fk + 4 * reg;
         if (i < g.M && j < g.N) {
           const double v = acc[mi][ni][reg];
-          if (partial) {
+          if (to_planes) {
             g.part[((size_t)zidx * g.M + i) * g.N + j] = v;
           } else {
             double o = g.alpha * v;
@@ -353,7 +379,6 @@ __global__ void splitk_reduce_kernel(GemmArgs g, int nsplit) {
   if (idx >= (long)g.M * g.N) return;
   const int i = (int)(idx / g.N), j = (int)(idx % g.N);
   double v = 0.0;
-  if (g.wl) nsplit = g.nz[(g.klist_on_rows ? i : j) / GB];   // this tile's own number of pieces
   for (int z = 0; z < nsplit; ++z) v += g.part[((size_t)z * g.M + i) * g.N + j];  // fixed order
   double o = g.alpha * v;
   if (g.E) o += g.beta * g.E[(size_t)i * g.e_is + (size_t)j * g.e_js];
@@ -364,7 +389,7 @@ __global__ void splitk_reduce_kernel(GemmArgs g, int nsplit) {
 int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double *A, long a_is, long a_ks,
                 const double *B, long b_ks, long b_js, double beta, const double *E, long e_is, long e_js,
                 double *C, long c_is, long c_js, double *work, size_t work_elems, double gamma,
-                const double *E2, const GemmStageList *sl) {
+                const double *E2, int *tickets) {
   if (M <= 0 || N <= 0) return FLGP_OK;
   GemmArgs g;
   // orient so that the contiguous output dimension is the kernel's column dimension
@@ -381,40 +406,15 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
     g.E = E; g.e_is = e_is; g.e_js = e_js;
     g.C = C; g.c_is = c_is; g.c_js = c_js;
   }
-  g.klist = nullptr; g.nk = nullptr; g.klist_ld = 0; g.klist_on_rows = 0;
-  g.wl = nullptr; g.nz = nullptr; g.n_other = 1; g.zmax = 1;
-  g.packed = nullptr; g.off = nullptr;
-  if (sl && sl->klist) {
-    // the list describes the k stages that matter for each tile of the operand the CALLER passed as A (sl->on_a)
-    // or as B; after the orientation swap above that operand may have become the other one
-    const bool swapped = (c_is == 1 && c_js != 1);
-    g.klist = sl->klist; g.nk = sl->nk; g.klist_ld = sl->ld;
-    g.klist_on_rows = (sl->on_a != swapped) ? 1 : 0;
-    if (sl->packed && g.klist_on_rows && tuning("gemm_bs_packed", 1)) { g.packed = sl->packed; g.off = sl->off; }
-  }
+  g.tickets = (work && tuning("gemm_fused_reduce", 0)) ? tickets : nullptr;
   g.alpha = alpha; g.beta = beta; g.gamma = gamma;
   g.E2 = (gamma == 0.0) ? nullptr : E2;
   if (beta == 0.0) g.E = nullptr;
   const int ntiles = ceil_div(g.M, GB) * ceil_div(g.N, GB);
+  if (ntiles > GEMM_MAX_TICKETS) g.tickets = nullptr;
+  // one partial plane: M x N doubles for the reduction kernel, whole 128 x 128 tiles for the in-kernel reduction
+  const size_t per = g.tickets ? (size_t)ntiles * PLANE : (size_t)g.M * g.N;
   int nsplit = 1;
-  if (g.klist) {
-    // block-sparse: the work is sl->total_stages tile-stages; aim at ~8 stages per block, at most 512 blocks
-    if (work) {
-      long want = sl->total_stages * (long)ceil_div(g.klist_on_rows ? g.N : g.M, GB) / 8;
-      if (want > 512) want = 512;
-      nsplit = (int)(want / ntiles);
-      if (nsplit > sl->max_stages / 4) nsplit = sl->max_stages / 4;
-      if (tuning("gemm_bs_nsplit", 0) > 0) nsplit = tuning("gemm_bs_nsplit", 0);
-      const size_t per = (size_t)g.M * g.N;
-      if (sl->wl && (size_t)sl->zmax * per <= work_elems && tuning("gemm_bs_balanced", 1)) {
-        g.wl = sl->wl; g.nz = sl->nz; g.zmax = sl->zmax;
-        g.n_other = ceil_div(g.klist_on_rows ? g.N : g.M, GB);
-        nsplit = 1;
-      }
-      if ((size_t)nsplit * per > work_elems) nsplit = (int)(work_elems / per);
-      if (nsplit < 1) nsplit = 1;
-    }
-  } else
   if (work && ntiles < 256 && Kd >= 8 * GK) {
     nsplit = 512 / ntiles;
     // at least gemm_min_stages (default 5) stages per block: with fewer, the partial planes (and the reduction that
@@ -422,29 +422,27 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
     // eigensolver spent 33 us in the reduction of 128 planes next to 26 us in the GEMM
     const int maxk = Kd / (tuning("gemm_min_stages", 5) * GK);
     if (nsplit > maxk) nsplit = maxk;
-    const size_t per = (size_t)g.M * g.N;
     if ((size_t)nsplit * per > work_elems) nsplit = (int)(work_elems / per);
     if (nsplit < 1) nsplit = 1;
   }
   int klen = ceil_div(Kd > 0 ? Kd : 1, nsplit);
   klen = (klen + GK - 1) / GK * GK;
-  if (!g.klist) nsplit = ceil_div(Kd > 0 ? Kd : 1, klen);
+  nsplit = ceil_div(Kd > 0 ? Kd : 1, klen);
   g.ksplit_len = klen;
   g.part = work;
   // overlapping tiles write some elements twice: harmless unless the epilogue reads what it overwrites
-  g.shift_edges = g.klist ? 0 : (nsplit > 1 || ((const double *)g.C != g.E && (const double *)g.C != g.E2)) ? 1 : 0;
+  // (with the reduction kernel every element is written exactly once, by that kernel, whatever the tiles overlap)
+  const bool aliased = (const double *)g.C == g.E || (const double *)g.C == g.E2;
+  g.shift_edges = ((nsplit > 1 && !g.tickets) || !aliased) ? 1 : 0;
   {
-    // flops actually multiplied: with a stage list only the listed 16-deep stages of each 128-wide tile
-    const double fl = g.klist ? 2.0 * 16.0 * (double)GB * (double)sl->total_stages * (double)(g.klist_on_rows ? g.N : g.M)
-                              : 2.0 * (double)M * (double)N * (double)Kd;
+    const double fl = 2.0 * (double)M * (double)N * (double)Kd;
     ProfScope ps("gemm_f64_kernel", st, fl);
     // second record per shape class (large / medium / small) for the bench breakdown
     ProfScope ps2(fl > 5e9 ? "gemm_large" : (fl > 2e8 ? "gemm_medium" : "gemm_small"), st, fl);
-    if (g.wl) hipLaunchKernelGGL(gemm_f64_kernel, dim3(sl->n_items * g.n_other, 1, 1), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL(gemm_f64_kernel, dim3(ntiles, 1, nsplit), dim3(256), 0, st, g);
+    hipLaunchKernelGGL(gemm_f64_kernel, dim3(ntiles, 1, nsplit), dim3(256), 0, st, g);
   }
   FLGP_TRY(check_launch("gemm_f64_kernel"));
-  if (nsplit > 1 || (g.wl && g.zmax > 1)) {
+  if (!g.tickets && nsplit > 1) {
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div((long)g.M * g.N, 256)), dim3(256), 0, st, g, nsplit);
     FLGP_TRY(check_launch("splitk_reduce_kernel"));
   }
@@ -480,7 +478,7 @@ extern "C" int flgp_dev_gemm(void *stream, int M, int N, int Kd, double alpha, c
                              size_t work_elems) {
   FLGP_REQUIRE(M >= 0 && N >= 0 && Kd >= 0 && A && B && C, "gemm: bad arguments");
   return gemm_launch((hipStream_t)stream, M, N, Kd, alpha, A, a_is, a_ks, B, b_ks, b_js, beta, E, e_is, e_js, C,
-                     c_is, c_js, d_work, work_elems, 0.0, nullptr, nullptr);
+                     c_is, c_js, d_work, work_elems, 0.0, nullptr);
 }
 
 extern "C" int flgp_dev_gather_rows(void *stream, const double *dV, int ld, const int *d_idx, int n0, int K,

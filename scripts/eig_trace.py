@@ -1,0 +1,35 @@
+"""GPU box: build the C3 Gram matrix once, then run the top-K eigensolver a few times (for rocprofv3 --kernel-trace).
+usage: python3 scripts/eig_trace.py [reps] [key=value tuning ...]"""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np, torch
+from flgp_amd import _lib, synth
+from flgp_amd.pipeline import HeatKernelPath, HipStages, PathConfig
+
+reps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+n, d, s, r, K = int(os.environ.get("N", 1_000_000)), 16, int(os.environ.get("S", 5000)), 10, int(os.environ.get("K", 200))
+dev = torch.device("cuda", 0)
+S = HipStages(dev); P = HeatKernelPath(S); L = _lib.lib()
+for kv in sys.argv[2:]:
+    k, v = kv.split("="); L.flgp_set_tuning(k.encode(), int(v))
+X_np = synth.gaussian_mixture(n, d)
+X = torch.from_numpy(np.ascontiguousarray(X_np.T)).to(dev)
+sel = np.sort(synth.random_anchor_rows(n, s))
+U = torch.from_numpy(np.ascontiguousarray(X_np[sel, :].T)).to(dev)
+anchors = S.anchor_prep(U)
+num_class = P.cluster_sizes(X, anchors)
+knn_idx, _ = S.knn(X, anchors, r)
+ei, ev = S.lae(X, anchors, knn_idx)
+csc = S.csc(ei, s)
+c = S.colsum(ev, csc); S.col_scale(ei, ev, c, num_class, 0); S.row_normalize(ev)
+c2 = S.colsum(ev, csc); S.col_scale(ei, ev, c2, None, 1)
+G = S.gram(ei, ev, csc)
+torch.cuda.synchronize()
+ts = []
+for it in range(reps):
+    t0 = time.perf_counter()
+    eig, V, info = S.eig_topk(G, K)
+    torch.cuda.synchronize()
+    ts.append((time.perf_counter() - t0) * 1e3)
+print("eig ms:", " ".join("%.2f" % t for t in ts), info, "top", float(eig[0]), "K-th", float(eig[K - 1]))

@@ -366,7 +366,7 @@ def test_eig_degenerate_spectrum_falls_back(oracle, stages):
 
 def test_eig_blocksparse_matches_dense(stages):
     """The Gram matrix of a neighbourhood graph is sparse; from s = 3072 on the solver permutes it and multiplies
-    only the populated 16 x 128 blocks (+ a CSR remainder).  That must not change the result beyond rounding:
+    only the populated 64 x 16 blocks (+ a CSR remainder).  That must not change the result beyond rounding:
     same eigenpairs as the dense path and as LAPACK, for a manifold (swiss roll) and for clustered data, and for
     a matrix without structure (where the solver must notice and stay dense)."""
     from flgp_amd import _lib
@@ -399,6 +399,45 @@ def test_eig_blocksparse_matches_dense(stages):
             np.testing.assert_allclose(out[1][0], out[0][0], rtol=1e-10, atol=1e-13)
     finally:
         L.flgp_set_tuning(b"eig_blocksparse", 1)
+
+
+@pytest.mark.parametrize("s,b,density", [(700, 48, 0.03), (1100, 64, 0.02), (2000, 256, 0.01), (1536, 80, 0.05)])
+def test_blocksparse_product_matches_dense(stages, s, b, density):
+    """csrc/bsg.hip on its own: alpha G X + beta E through the ordering, the kept 64 x 16 blocks (MFMA) and the CSR
+    remainder equals the dense product to rounding -- for a banded-plus-scattered symmetric matrix (blocks AND a
+    remainder, tile / stage / column-tile edges that do not divide s or b), including rows without any entry."""
+    import ctypes
+    L = _lib.lib()
+    rng = np.random.default_rng(s + b)
+    G = np.zeros((s, s))
+    band = max(8, int(density * s))
+    for off in range(band):                                   # a band: concentrates after the ordering
+        v = rng.uniform(0.1, 1.0, s - off)
+        G[np.arange(s - off), np.arange(off, s)] = v
+    scat = rng.integers(0, s, size=(4 * s, 2))                # scattered entries: the CSR remainder
+    G[scat[:, 0], scat[:, 1]] = rng.uniform(0.1, 1.0, len(scat))
+    hub = rng.integers(0, s, size=300)                        # one hub row with a few hundred entries
+    G[7, hub] = rng.uniform(0.1, 1.0, 300)
+    G = 0.5 * (G + G.T)
+    G[s // 3, :] = 0.0; G[:, s // 3] = 0.0                    # an isolated anchor
+    pi = rng.permutation(s)                                   # hide the band
+    G = np.ascontiguousarray(G[np.ix_(pi, pi)])
+    X = rng.normal(size=(s, b)); E = rng.normal(size=(s, b))
+    dG = torch.from_numpy(G).cuda(); dX = cm(X); dE = cm(E)
+    out = torch.empty((b, s), dtype=torch.float64, device="cuda")
+    wb = L.flgp_dev_bsg_workspace(s, b)
+    work = torch.empty((wb // 8 + 1,), dtype=torch.float64, device="cuda")
+    info = (ctypes.c_int * 4)()
+    st = torch.cuda.current_stream().cuda_stream
+    for alpha, beta, e in ((1.0, 0.0, None), (0.7, -1.3, dE)):
+        _lib.check(L.flgp_dev_bsg_apply(st, dG.data_ptr(), s, s, dX.data_ptr(), b, alpha, beta,
+                                        e.data_ptr() if e is not None else None, out.data_ptr(), work.data_ptr(), wb,
+                                        ctypes.addressof(info)))
+        ref = alpha * (G @ X) + (beta * E if e is not None else 0.0)
+        got = to_np_cm(out)
+        assert info[1] == np.count_nonzero(G)
+        assert info[2] > 0 and info[3] > 0, "the case must exercise both the blocks and the remainder"
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
 
 
 # ------------------------------------------------------------------------------ spectrum + heat kernel
