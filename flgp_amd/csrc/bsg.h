@@ -9,6 +9,7 @@
 // work is skipped, never a result beyond rounding.
 #pragma once
 #include "common.h"
+#include <vector>
 
 namespace flgp {
 
@@ -44,14 +45,16 @@ struct BsG {
   int *head = nullptr;            // work-queue heads of the product kernel (ring of 2)
   double *T[3] = {nullptr, nullptr, nullptr};   // b x s blocks of the transposed filter
   int h_meta[BSG_META] = {0};     // host copy, valid after the stream has been synchronised
-  int launches = 0;               // products issued (selects the queue head)
+  int launches = 0;               // products issued
+  std::vector<int> h_perm;        // source of an asynchronous upload: lives as long as the struct
 };
 
 size_t bsg_workspace_bytes(int s, int b);
 // carve the members out of a workspace (advances p)
 void bsg_carve(BsG &g, char *&p, int s, int b);
 // Enqueues the whole set-up (one host round trip in the middle, for the 64-cluster chain).  On return the device work
-// is queued and the bookkeeping is on its way to g.h_meta; call bsg_finish() after the next stream synchronisation.
+// is queued and the bookkeeping is on its way to g.h_meta: call bsg_finish() after the next stream synchronisation and
+// before the first product.
 int bsg_setup(hipStream_t st, const double *dG, int ldg, int s, BsG &g);
 // after a synchronisation: decides g.on (false when G does not concentrate: the caller multiplies with the dense G)
 void bsg_finish(BsG &g);

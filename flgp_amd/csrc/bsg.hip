@@ -187,19 +187,28 @@ __global__ __launch_bounds__(256) void bsg_label_hop_kernel(const int *__restric
   }
 }
 
-// C(p, q) = sum over the rows with label p of Y(row, q): one workgroup per p, rows in ascending order per quarter
-__global__ __launch_bounds__(256) void bsg_cluster_weights_kernel(const double *__restrict__ Y, const int *__restrict__ lab,
-                                                                  const int *__restrict__ meta, int s,
-                                                                  double *__restrict__ C) {
-  __shared__ double part[4][BSG_SEEDS];
+// C(p, q) = sum over the rows with label p of Y(row, q), in two levels with a fixed order: a workgroup adds its chunk
+// of 64 rows into a 65 x 64 table in LDS (thread q owns column q: no conflicts, rows in ascending order), a second
+// launch adds the chunk tables in ascending chunk order.
+constexpr int BSG_CW_ROWS = 64;
+__global__ __launch_bounds__(64) void bsg_cluster_partial_kernel(const double *__restrict__ Y, const int *__restrict__ lab,
+                                                                 const int *__restrict__ meta, int s,
+                                                                 double *__restrict__ part) {
+  __shared__ double tab[(BSG_SEEDS + 1) * BSG_SEEDS];
   if (meta[BSG_M_OFF]) return;
-  const int p = blockIdx.x, q = threadIdx.x & 63, quarter = threadIdx.x >> 6;
+  const int q = threadIdx.x, i0 = blockIdx.x * BSG_CW_ROWS;
+  for (int p = 0; p <= BSG_SEEDS; ++p) tab[p * BSG_SEEDS + q] = 0.0;
+  const int i1 = (i0 + BSG_CW_ROWS < s) ? i0 + BSG_CW_ROWS : s;
+  for (int i = i0; i < i1; ++i) tab[lab[i] * BSG_SEEDS + q] += Y[(size_t)i * BSG_SEEDS + q];
+  for (int p = 0; p < BSG_SEEDS; ++p) part[((size_t)blockIdx.x * BSG_SEEDS + p) * BSG_SEEDS + q] = tab[p * BSG_SEEDS + q];
+}
+__global__ __launch_bounds__(256) void bsg_cluster_sum_kernel(const double *__restrict__ part, int nchunk,
+                                                              const int *__restrict__ meta, double *__restrict__ C) {
+  if (meta[BSG_M_OFF]) return;
+  const int e = blockIdx.x * 256 + threadIdx.x;    // e = p * 64 + q
   double acc = 0.0;
-  for (int i = quarter; i < s; i += 4)
-    if (lab[i] == p) acc += Y[(size_t)i * BSG_SEEDS + q];
-  part[quarter][q] = acc;
-  __syncthreads();
-  if (quarter == 0) C[(size_t)p * BSG_SEEDS + q] = ((part[0][q] + part[1][q]) + part[2][q]) + part[3][q];
+  for (int c = 0; c < nchunk; ++c) acc += part[(size_t)c * BSG_SEEDS * BSG_SEEDS + e];
+  C[e] = acc;
 }
 
 __global__ void bsg_iperm_kernel(const int *__restrict__ perm, int s, int *__restrict__ iperm) {
@@ -207,15 +216,24 @@ __global__ void bsg_iperm_kernel(const int *__restrict__ perm, int s, int *__res
   if (i < s) iperm[perm[i]] = i;
 }
 
-// non-zeros per (64-row tile, 16-deep stage) of P G P^T
+// non-zeros per (64-row tile, 16-deep stage) of P G P^T: one workgroup per tile gathers its 64 rows' entries into a
+// histogram in LDS (no global atomics: the kept blocks take ~500 increments each)
 __global__ __launch_bounds__(256) void bsg_count_kernel(const int *__restrict__ gptr, const int *__restrict__ gcol,
-                                                        const int *__restrict__ iperm, int s, int nstage,
-                                                        int *__restrict__ cnt) {
-  const int lane = threadIdx.x & 63, i = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (i >= s) return;
-  int *row = cnt + (size_t)(iperm[i] / BSG_TM) * nstage;
-  const int e1 = gptr[i + 1];
-  for (int e = gptr[i] + lane; e < e1; e += 64) atomicAdd(&row[iperm[gcol[e]] >> 4], 1);
+                                                        const int *__restrict__ perm, const int *__restrict__ iperm, int s,
+                                                        int nstage, int *__restrict__ cnt) {
+  extern __shared__ int hist[];
+  const int t = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int g = threadIdx.x; g < nstage; g += 256) hist[g] = 0;
+  __syncthreads();
+  for (int r = wave; r < BSG_TM; r += 4) {
+    const int ip = t * BSG_TM + r;
+    if (ip >= s) break;
+    const int i = perm[ip];
+    const int e1 = gptr[i + 1];
+    for (int e = gptr[i] + lane; e < e1; e += 64) atomicAdd(&hist[iperm[gcol[e]] >> 4], 1);
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < nstage; g += 256) cnt[(size_t)t * nstage + g] = hist[g];
 }
 
 // One workgroup turns the counts into the block lists: per tile the stages with >= BSG_DENSE_MIN non-zeros (ascending),
@@ -566,20 +584,11 @@ static size_t bsg_pack_cap(int s) {
   return nt * ng / 2 + 1;
 }
 
-size_t bsg_workspace_bytes(int s, int b) {
-  const size_t nt = (s + BSG_TM - 1) / BSG_TM, ng = (s + BSG_SK - 1) / BSG_SK;
-  const size_t cap = bsg_csr_cap(s), rcap = cap / 4 + 64;
-  size_t tot = 0;
-  tot += al(sizeof(int) * (s + 1)) + al(sizeof(int) * cap) + al(sizeof(double) * cap);                 // CSR
-  tot += 4 * al(sizeof(int) * (size_t)s);                                                              // lab x2, perm, iperm
-  tot += 2 * al(sizeof(double) * (size_t)s * BSG_SEEDS) + al(sizeof(double) * BSG_SEEDS * BSG_SEEDS);   // E0, E1, C
-  tot += 2 * al(sizeof(int) * nt * ng) + 4 * al(sizeof(int) * (nt + 1)) + al(sizeof(int) * nt * ng);    // cnt, blkpos, nk/off/order, klist
-  tot += al(sizeof(double) * BSG_BLK * bsg_pack_cap(s));
-  tot += 2 * al(sizeof(int) * (s + 1)) + al(sizeof(int) * rcap) + al(sizeof(double) * rcap);            // remainder
-  tot += 2 * al(sizeof(double) * (size_t)s) + al(sizeof(double) * 2);                                   // colabs, diag, bounds
-  tot += al(sizeof(int) * BSG_META) + al(sizeof(int) * 4);
-  tot += 3 * al(sizeof(double) * (size_t)s * b);
-  return tot;
+size_t bsg_workspace_bytes(int s, int b) {   // what bsg_carve takes, measured by carving at address 0
+  BsG g;
+  char *p = nullptr;
+  bsg_carve(g, p, s, b);
+  return (size_t)(p - (char *)nullptr) + 256;
 }
 
 void bsg_carve(BsG &g, char *&p, int s, int b) {
@@ -589,11 +598,14 @@ void bsg_carve(BsG &g, char *&p, int s, int b) {
   g.csr_cap = bsg_csr_cap(s); g.rem_cap = g.csr_cap / 4 + 64; g.pack_cap = bsg_pack_cap(s);
   g.gptr = (int *)take(sizeof(int) * (s + 1)); g.gcol = (int *)take(sizeof(int) * g.csr_cap);
   g.gval = (double *)take(sizeof(double) * g.csr_cap);
-  g.lab = (int *)take(sizeof(int) * (size_t)s); int *lab2 = (int *)take(sizeof(int) * (size_t)s);
+  // C, meta and the labels are read back by the host in one copy: adjacent, in this order
+  g.Cw = (double *)take(sizeof(double) * BSG_SEEDS * BSG_SEEDS + sizeof(int) * (BSG_META + (size_t)s));
+  g.meta = (int *)(g.Cw + BSG_SEEDS * BSG_SEEDS);
+  g.lab = g.meta + BSG_META;
+  int *lab2 = (int *)take(sizeof(int) * (size_t)s);
   g.perm = (int *)take(sizeof(int) * (size_t)s); g.iperm = (int *)take(sizeof(int) * (size_t)s);
   g.rcnt = lab2;   // the second label buffer is free again once the ordering is done; (s + 1 ints are not needed: s suffice)
   g.E0 = (double *)take(sizeof(double) * (size_t)s * BSG_SEEDS); g.E1 = (double *)take(sizeof(double) * (size_t)s * BSG_SEEDS);
-  g.Cw = (double *)take(sizeof(double) * BSG_SEEDS * BSG_SEEDS);
   g.cnt = (int *)take(sizeof(int) * nt * ng); g.blkpos = (int *)take(sizeof(int) * nt * ng);
   g.nk = (int *)take(sizeof(int) * (nt + 1)); g.off = (int *)take(sizeof(int) * (nt + 1));
   g.order = (int *)take(sizeof(int) * (nt + 1)); (void)take(sizeof(int) * (nt + 1));
@@ -603,7 +615,7 @@ void bsg_carve(BsG &g, char *&p, int s, int b) {
   g.rcol = (int *)take(sizeof(int) * g.rem_cap); g.rval = (double *)take(sizeof(double) * g.rem_cap);
   g.colabs = (double *)take(sizeof(double) * (size_t)s); g.diag = (double *)take(sizeof(double) * (size_t)s);
   g.bounds = (double *)take(sizeof(double) * 2);
-  g.meta = (int *)take(sizeof(int) * BSG_META); g.head = (int *)take(sizeof(int) * 4);
+  g.head = (int *)take(sizeof(int) * 4);
   for (int q = 0; q < 3; ++q) g.T[q] = (double *)take(sizeof(double) * (size_t)s * b);
 }
 
@@ -628,15 +640,22 @@ int bsg_setup(hipStream_t st, const double *dG, int ldg, int s, BsG &g) {
                      (double *)nullptr);
   hipLaunchKernelGGL(bsg_label_hop_kernel, dim3(rows4), dim3(256), 0, st, g.gptr, g.gcol, g.gval, g.meta, g.lab, s,
                      (int *)nullptr, g.E1);
-  hipLaunchKernelGGL(bsg_cluster_weights_kernel, dim3(BSG_SEEDS), dim3(256), 0, st, g.E1, g.lab, g.meta, s, g.Cw);
+  {
+    const int nchunk = ceil_div(s, BSG_CW_ROWS);     // chunk tables: s/64 x 4096 doubles = the size of E0, free by now
+    hipLaunchKernelGGL(bsg_cluster_partial_kernel, dim3(nchunk), dim3(64), 0, st, g.E1, g.lab, g.meta, s, g.E0);
+    hipLaunchKernelGGL(bsg_cluster_sum_kernel, dim3(BSG_SEEDS * BSG_SEEDS / 256), dim3(256), 0, st, g.E0, nchunk, g.meta, g.Cw);
+  }
   FLGP_TRY(check_launch("bsg ordering"));
   const int p = BSG_SEEDS;
-  std::vector<int> lab(s);
-  std::vector<double> C((size_t)p * p);
-  FLGP_HIP(hipMemcpyAsync(lab.data(), g.lab, sizeof(int) * s, hipMemcpyDeviceToHost, st));
-  FLGP_HIP(hipMemcpyAsync(C.data(), g.Cw, sizeof(double) * p * p, hipMemcpyDeviceToHost, st));
-  FLGP_HIP(hipMemcpyAsync(g.h_meta, g.meta, sizeof(int) * BSG_META, hipMemcpyDeviceToHost, st));
+  // one copy for the three things the host needs: C (p x p doubles), meta, labels are adjacent in the workspace
+  std::vector<double> xfer((size_t)p * p + (BSG_META * sizeof(int) + sizeof(int) * (size_t)s + 7) / 8 + 1);
+  FLGP_HIP(hipMemcpyAsync(xfer.data(), g.Cw, sizeof(double) * p * p + sizeof(int) * (BSG_META + (size_t)s), hipMemcpyDeviceToHost, st));
   FLGP_HIP(stream_wait(st));
+  const double *C = xfer.data();
+  memcpy(g.h_meta, xfer.data() + (size_t)p * p, sizeof(int) * BSG_META);
+  const int *lab = (const int *)(xfer.data() + (size_t)p * p) + BSG_META;
+  for (int q = 0; q < p * p; ++q)
+    if (!std::isfinite(C[q])) { set_error("block-sparse ordering: the matrix is not finite"); return FLGP_ERR_INVALID; }
   if (g.h_meta[BSG_M_OFF]) return FLGP_OK;     // denser than the CSR allows: the caller stays with the dense products
   // chain the clusters: start at the heaviest, always continue with the unused cluster most strongly tied to the last
   std::vector<int> order, rank(p + 1, p);
@@ -658,7 +677,9 @@ int bsg_setup(hipStream_t st, const double *dG, int ldg, int s, BsG &g) {
     }
     for (int q = 0; q < p; ++q) rank[order[q]] = q;   // label p (isolated anchors) keeps rank p: last
   }
-  std::vector<int> perm(s), start(p + 2, 0);
+  std::vector<int> &perm = g.h_perm;
+  perm.assign(s, 0);
+  std::vector<int> start(p + 2, 0);
   for (int i = 0; i < s; ++i) {
     if (lab[i] < 0 || lab[i] > p) { set_error("block-sparse ordering: bad label"); return FLGP_ERR_HIP; }
     ++start[rank[lab[i]] + 1];
@@ -667,8 +688,8 @@ int bsg_setup(hipStream_t st, const double *dG, int ldg, int s, BsG &g) {
   for (int i = 0; i < s; ++i) perm[start[rank[lab[i]]]++] = i;   // stable counting sort by cluster rank
   FLGP_HIP(hipMemcpyAsync(g.perm, perm.data(), sizeof(int) * s, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(bsg_iperm_kernel, dim3(ceil_div(s, 256)), dim3(256), 0, st, g.perm, s, g.iperm);
-  FLGP_HIP(hipMemsetAsync(g.cnt, 0, sizeof(int) * (size_t)g.ntile * g.nstage, st));
-  hipLaunchKernelGGL(bsg_count_kernel, dim3(rows4), dim3(256), 0, st, g.gptr, g.gcol, g.iperm, s, g.nstage, g.cnt);
+  hipLaunchKernelGGL(bsg_count_kernel, dim3(g.ntile), dim3(256), sizeof(int) * g.nstage, st, g.gptr, g.gcol, g.perm, g.iperm, s,
+                     g.nstage, g.cnt);
   hipLaunchKernelGGL(bsg_lists_kernel, dim3(1), dim3(1024), 0, st, g.cnt, g.ntile, g.nstage, (long)g.pack_cap, g.blkpos,
                      g.nk, g.off, g.klist, g.order, g.meta);
   hipLaunchKernelGGL(bsg_pack_kernel, dim3(g.nstage, g.ntile), dim3(256), 0, st, dG, ldg, s, g.nstage, g.perm, g.blkpos,
@@ -680,12 +701,8 @@ int bsg_setup(hipStream_t st, const double *dG, int ldg, int s, BsG &g) {
                      s, g.nstage, g.rptr, g.rcnt, g.rcol, g.rval, 1);
   FLGP_TRY(check_launch("bsg lists"));
   FLGP_HIP(hipMemcpyAsync(g.h_meta, g.meta, sizeof(int) * BSG_META, hipMemcpyDeviceToHost, st));
-  // `perm` is a host vector: its copy has to be done before it dies.  This wait is short: only the tiny kernels above
-  // are queued behind the copy.
-  FLGP_HIP(stream_wait(st));
-  g.built = true;
+  g.built = true;       // (g.h_perm, the source of the copy above, lives as long as g)
   g.launches = 0;
-  bsg_finish(g);
   return FLGP_OK;
 }
 
@@ -758,6 +775,8 @@ extern "C" int flgp_dev_bsg_apply(void *stream, const double *dG, int ldg, int s
   char *p = (char *)d_work;
   bsg_carve(g, p, s, b);
   FLGP_TRY(bsg_setup(st, dG, ldg, s, g));
+  FLGP_HIP(hipStreamSynchronize(st));
+  bsg_finish(g);
   if (info) {
     info[0] = g.on ? 1 : 0; info[1] = g.h_meta[BSG_M_NNZ]; info[2] = g.h_meta[BSG_M_TOTAL]; info[3] = g.h_meta[BSG_M_RNNZ];
   }

@@ -32,6 +32,51 @@ int check_distance(const char *distance) {
   return FLGP_ERR_UNSUPPORTED;
 }
 
+// Input validation for the host entry points, on the device (the data is there anyway; a pass over 128 MB is 30 us).
+// flag |= 1 for a non-finite coordinate, |= 2 for a column index outside [0, s).
+__global__ void check_finite_kernel(const double *__restrict__ x, long count, int *__restrict__ flag) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += stride) {
+    const double v = x[e];
+    bad |= !(__builtin_fabs(v) <= 1.7976931348623157e308);     // false for NaN and +-Inf
+  }
+  if (bad) atomicOr(flag, 1);
+}
+__global__ void check_index_kernel(const int *__restrict__ idx, long count, int s, int *__restrict__ flag) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  bool bad = false;
+  for (long e = (long)blockIdx.x * blockDim.x + threadIdx.x; e < count; e += stride) bad |= (unsigned)idx[e] >= (unsigned)s;
+  if (bad) atomicOr(flag, 2);
+}
+struct InputCheck {
+  DevBuf flag;
+  int begin(hipStream_t st) {
+    FLGP_TRY(flag.alloc(sizeof(int)));
+    FLGP_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), st));
+    return FLGP_OK;
+  }
+  int finite(hipStream_t st, const double *d_x, long count) {
+    if (count <= 0) return FLGP_OK;
+    hipLaunchKernelGGL(check_finite_kernel, dim3((unsigned)std::min<long>(2048, (count + 255) / 256)), dim3(256), 0, st, d_x, count, flag.as<int>());
+    return check_launch("check_finite_kernel");
+  }
+  int indices(hipStream_t st, const int *d_idx, long count, int s) {
+    if (count <= 0) return FLGP_OK;
+    hipLaunchKernelGGL(check_index_kernel, dim3((unsigned)std::min<long>(2048, (count + 255) / 256)), dim3(256), 0, st, d_idx, count, s, flag.as<int>());
+    return check_launch("check_index_kernel");
+  }
+  // synchronises; FLGP_ERR_INVALID with the reason
+  int verdict(hipStream_t st, const char *who) {
+    int h = 0;
+    FLGP_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    FLGP_HIP(hipStreamSynchronize(st));
+    if (h & 1) { set_error("%s: the input holds NA / NaN / Inf values (the reference returns garbage here; this library refuses)", who); return FLGP_ERR_INVALID; }
+    if (h & 2) { set_error("%s: a column index of the sparse matrix is outside [0, s)", who); return FLGP_ERR_INVALID; }
+    return FLGP_OK;
+  }
+};
+
 int h2d(void *dst, const void *src, size_t bytes, hipStream_t st) {
   if (bytes) FLGP_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, st));
   return FLGP_OK;
@@ -65,6 +110,13 @@ int upload_points(Sim &S, hipStream_t st, const double *X, int n, int d, const d
   FLGP_TRY(S.uu.alloc(sizeof(double) * (size_t)rows));
   FLGP_TRY(h2d(S.X.p, X, sizeof(double) * (size_t)n * d, st));
   FLGP_TRY(h2d(S.U.p, U, sizeof(double) * (size_t)s * ucols, st));
+  {   // a NaN row would leave the k-NN lists empty (knn.hip); refuse before anything is computed from it
+    InputCheck ck;
+    FLGP_TRY(ck.begin(st));
+    FLGP_TRY(ck.finite(st, S.X.as<double>(), (long)n * d));
+    FLGP_TRY(ck.finite(st, S.U.as<double>(), (long)s * ucols));
+    FLGP_TRY(ck.verdict(st, "points / anchors"));
+  }
   return flgp_dev_anchor_prep(st, S.U.as<double>(), s, s, d, S.Ut.as<double>(), S.uu.as<double>());
 }
 
@@ -154,6 +206,22 @@ int spectrum(Sim &S, hipStream_t st, int K, int root, Spectrum &P, int *info) {
   FLGP_TRY(P.V.alloc(sizeof(double) * (size_t)S.s * K));
   FLGP_TRY(flgp_dev_eig_topk(st, P.G.as<double>(), S.s, S.s, K, 0.0, P.eig.as<double>(), P.V.as<double>(), S.s,
                              P.work.p, wb, info));
+  {
+    // u = A v / sigma needs sigma > 0.  K == s on a rank-deficient A, an anchor no point chose, an SE bandwidth that
+    // underflows a column: the Gram route cannot deliver those left vectors (the reference's BDCSVD can), and dividing
+    // would fill all of H with Inf / NaN.  flgp_dev_eig_topk has synchronised the stream: look at the values.
+    std::vector<double> hv((size_t)K);
+    FLGP_TRY(d2h(hv.data(), P.eig.p, sizeof(double) * (size_t)K, st));
+    FLGP_HIP(hipStreamSynchronize(st));
+    const double top = hv[0], low = hv[K - 1];
+    if (!(top > 0.0) || !std::isfinite(top)) { set_error("spectrum: the similarity matrix is zero or not finite"); return FLGP_ERR_INVALID; }
+    if (!(low > 1e-24 * top)) {
+      set_error("spectrum: singular value %d of A is zero to working precision (sigma^2 = %.3e, sigma_1^2 = %.3e): K = %d reaches "
+                "into the null space of the similarity matrix, whose left vectors the Gram route cannot recover -- choose a smaller K",
+                K, low, top, K);
+      return FLGP_ERR_NOCONV;
+    }
+  }
   // u = A v / sigma, vectors = u sqrt(n), values = sigma^2 (or sigma if root)  (:153-158)
   FLGP_TRY(P.values.alloc(sizeof(double) * (size_t)K));
   FLGP_TRY(P.vectors.alloc(sizeof(double) * (size_t)S.n * K));
@@ -281,6 +349,12 @@ extern "C" int flgp_graph_laplacian(const int *csr_j, double *csr_x, int n, int 
   FLGP_TRY(alloc_ell(S));
   FLGP_TRY(h2d(S.ell_idx.p, csr_j, sizeof(int) * (size_t)n * r, st.s));
   FLGP_TRY(h2d(S.ell_val.p, csr_x, sizeof(double) * (size_t)n * r, st.s));
+  {   // the column indices become addresses in the CSC / Gram kernels
+    InputCheck ck;
+    FLGP_TRY(ck.begin(st.s));
+    FLGP_TRY(ck.indices(st.s, S.ell_idx.as<int>(), (long)n * r, s));
+    FLGP_TRY(ck.verdict(st.s, "graph_laplacian"));
+  }
   if (num_class) {
     FLGP_TRY(S.num_class.alloc(sizeof(double) * (size_t)s));
     FLGP_TRY(h2d(S.num_class.p, num_class, sizeof(double) * (size_t)s, st.s));
@@ -301,6 +375,13 @@ extern "C" int flgp_spectrum_from_Z(const int *csr_j, const double *csr_x, int n
   FLGP_TRY(alloc_ell(S));
   FLGP_TRY(h2d(S.ell_idx.p, csr_j, sizeof(int) * (size_t)n * r, st.s));
   FLGP_TRY(h2d(S.ell_val.p, csr_x, sizeof(double) * (size_t)n * r, st.s));
+  {
+    InputCheck ck;
+    FLGP_TRY(ck.begin(st.s));
+    FLGP_TRY(ck.indices(st.s, S.ell_idx.as<int>(), (long)n * r, s));
+    FLGP_TRY(ck.finite(st.s, S.ell_val.as<double>(), (long)n * r));
+    FLGP_TRY(ck.verdict(st.s, "spectrum_from_Z"));
+  }
   Spectrum P;
   FLGP_TRY(spectrum(S, st.s, K, root, P, nullptr));
   FLGP_TRY(d2h(values, P.values.p, sizeof(double) * (size_t)P.K, st.s));

@@ -1272,7 +1272,8 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   // subspace sits near the mean eigenvalue); the span p(G) Q does not depend on the basis.  So the first filter runs
   // straight on the start block with a-priori bounds -- damped interval [0, trace / s], scaled at the 1-norm -- and the
   // first Rayleigh-Ritz step (two Jacobi sweeps, two rotations, a host round trip) is saved.
-  const bool skip_rr0 = tuning("eig_skip_rr0", 1) != 0;
+  const int skip_rr_n = tuning("eig_skip_rr0", 1) ? std::max(1, tuning("eig_skip_rr_n", 1)) : 0;   // iterations without Rayleigh-Ritz
+  const bool skip_rr0 = skip_rr_n > 0;
   double h_apriori[2 * APRIORI_BLOCKS];
   if (skip_rr0 && !bs.built) {
     hipLaunchKernelGGL(apriori_bounds_kernel, dim3(APRIORI_BLOCKS), dim3(256), 0, st, dG, ldg, s, w.apriori);
@@ -1286,6 +1287,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   } else {
     FLGP_TRY(orth(F[0], Q, &cond));
   }
+  bsg_finish(bs);   // (the orthonormalisation has synchronised the stream: the set-up's bookkeeping has arrived)
 
   std::vector<double> theta(b), res(K);
   int gprods = 0, it = 0;
@@ -1416,7 +1418,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     // (rmax_prev is then advanced by the measured per-iteration contraction `rate`, so that the Rayleigh-
     //  Ritz step and its convergence test land on the iteration where the tolerance is expected to be met)
     const bool near_done = rmax_prev * rate <= 4.0 * tol;
-    const bool early_skip = (tuning("eig_skip_it1", 0) && it == 1) || (skip_rr0 && it == 0);
+    const bool early_skip = (tuning("eig_skip_it1", 0) && it == 1) || it < skip_rr_n;
     const bool do_rr = !early_skip && !(rr_every > 1 && it >= 3 && rmax_prev < 1e-6 * tuning("eig_rr_skip_below_e6", 1000) && since_rr + 1 < rr_every && !near_done);
     // Late Rayleigh-Ritz steps only refine a nearly diagonal T: the filter does not wait for them.  It is
     // linear, p(G) (Q W) = (p(G) Q) W, so it runs on the block as it is, with the bounds of the previous
@@ -1483,10 +1485,10 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
       } else {
         ++since_rr;
         A = Q; B = Z; free1 = F[1]; free2 = F[2];
-        if (it > 0) rmax_prev *= rate;
+        if (it >= skip_rr_n) rmax_prev *= rate;
       }
       FilterPlan fp;
-      if (it == 0 && skip_rr0) {   // (the start orthonormalisation has synchronised the stream: h_apriori is valid)
+      if (it < skip_rr_n) {   // (the start orthonormalisation has synchronised the stream: h_apriori is valid)
         double n1 = 0.0, tr = 0.0;
         if (bs.built) { n1 = bs.h_bounds[0]; tr = bs.h_bounds[1]; }   // gathered by the block-sparse set-up's pass over G
         else for (int q = 0; q < APRIORI_BLOCKS; ++q) { n1 = std::max(n1, h_apriori[q]); tr += h_apriori[APRIORI_BLOCKS + q]; }
@@ -1496,7 +1498,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
         if (cut0 > 0.5 * n1) cut0 = 0.5 * n1;
         fp.c = fp.e = 0.5 * cut0;
         fp.sigma1 = fp.e / (n1 - fp.c);
-        fp.m = std::max(2, tuning("eig_m0", 5));
+        fp.m = std::max(2, it == 0 ? tuning("eig_m0", 8) : tuning("eig_m1", 6));
         top = n1;
       } else {
         fp = plan_filter(top, it);
@@ -1513,7 +1515,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     //      no longer mixes eigen-directions and the next T stays diagonal up to the guard block.
     //      (Not after the a-priori filter of iteration 0: the start block is no Ritz basis, and projecting along its
     //      columns would take the block out of span p(G) Q.)
-    if (!(it == 0 && skip_rr0)) {
+    if (!(it < skip_rr_n)) {
       FLGP_TRY(gram_small(w.Qold, cur, w.T));
       hipLaunchKernelGGL(mask_strict_upper_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, w.T, b);
       FLGP_TRY(check_launch("mask_strict_upper_kernel"));

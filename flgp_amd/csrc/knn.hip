@@ -199,7 +199,10 @@ __global__ __launch_bounds__(256) void knn_kernel(const double *__restrict__ X, 
       for (int k = 0; k < RCAP; ++k) {
         const int slot = k - (RCAP - r);
         if (slot >= 0) {
-          idx_out[(size_t)slot * ldo + i] = top[p].bi[k];
+          // (a row of NaN / Inf coordinates never fills its list: the sentinel must not leave as an index -- every later
+          //  stage uses it as an address.  Such a row gets the anchors 0..r-1; the host entry points reject the input.)
+          const int bj_ = top[p].bi[k];
+          idx_out[(size_t)slot * ldo + i] = ((unsigned)bj_ < (unsigned)s) ? bj_ : slot;
           if (dist_out) dist_out[(size_t)slot * ldo + i] = top[p].bd[k];
         }
       }
@@ -335,7 +338,8 @@ __global__ __launch_bounds__(128) __attribute__((amdgpu_waves_per_eu(DP <= 32 ? 
     for (int k = 0; k < RCAP; ++k) {
       const int slot = k - (RCAP - r);
       if (slot >= 0) {
-        idx_out[(size_t)slot * ldo + i_own] = top.bi[k];
+        const int bj_ = top.bi[k];     // see knn_kernel: never let the sentinel out
+        idx_out[(size_t)slot * ldo + i_own] = ((unsigned)bj_ < (unsigned)s) ? bj_ : slot;
         if (dist_out) dist_out[(size_t)slot * ldo + i_own] = top.bd[k];
       }
     }
@@ -439,7 +443,7 @@ __global__ __launch_bounds__(128) void knn1_mfma_kernel(const double *__restrict
       }
       const long i = pbase + pt * 16 + fk + 4 * reg;
       if (fr == 0 && i < n) {
-        idx_out[i] = jmin;
+        idx_out[i] = ((unsigned)jmin < (unsigned)s) ? jmin : 0;   // (NaN row: see knn_kernel)
         if (dist_out) dist_out[i] = dmin;
       }
     }

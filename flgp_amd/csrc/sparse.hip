@@ -261,7 +261,8 @@ __global__ __launch_bounds__(256) void u_recover_kernel(const int *__restrict__ 
     if (k < K) {
       const double ev = eig[k];
       const double sigma = __builtin_sqrt(ev > 0.0 ? ev : 0.0);
-      out[(size_t)k * ldo + i] = (acc[kk] / sigma) * scale;
+      // sigma = 0 (K reaches into the null space of A): a zero column instead of Inf / NaN; the host entry points refuse
+      out[(size_t)k * ldo + i] = sigma > 0.0 ? (acc[kk] / sigma) * scale : 0.0;
     }
   }
 }
@@ -323,7 +324,7 @@ __global__ __launch_bounds__(256) void u_recover_tiled_kernel(const int *__restr
       for (int u = 0; u < UR; ++u) acc[u] += z[u] * v[u];
     }
 #pragma unroll
-    for (int u = 0; u < UR; ++u) tile[lane][il + u] = ((acc[u] * inv_guard) / sigma) * scale;
+    for (int u = 0; u < UR; ++u) tile[lane][il + u] = sigma > 0.0 ? ((acc[u] * inv_guard) / sigma) * scale : 0.0;
   }
   __syncthreads();
   const int i = tid & 63;

@@ -3,7 +3,7 @@ counts products / Rayleigh-Ritz steps for algorithm variants before they are wri
 usage: python3 scripts/model_chfsi.py G.npy [variant options k=v ...]"""
 import sys, time, numpy as np
 G = np.load(sys.argv[1]); s = G.shape[0]
-opt = dict(K=200, guard_pct=25, amp=8, amp_early=3, cut_pct=90, lock=0, skip_rr0=0, tol=5e-11, rr_every=3, amp_active=0, maxit=40, lock_q=16, guard_min=24, verbose=1)
+opt = dict(K=200, guard_pct=25, amp=8, amp_early=3, cut_pct=90, lock=0, skip_rr0=0, skip_n=1, m0=5, m1=5, tol=5e-11, rr_every=3, amp_active=0, maxit=40, lock_q=16, guard_min=24, verbose=1)
 for kv in sys.argv[2:]:
     k, v = kv.split("="); opt[k] = float(v) if "." in v or "e" in v else int(v)
 K = opt["K"]; tol = opt["tol"]
@@ -32,7 +32,7 @@ trace_mean = np.trace(G) / s
 for it in range(opt["maxit"]):
     ba = Q.shape[1]; Kact = K - XL.shape[1]
     Z = G @ Q; prods += 1
-    do_rr = not (opt["skip_rr0"] and it == 0)
+    do_rr = not (opt["skip_rr0"] and it < opt["skip_n"])
     near_done = rmax_prev * rate <= 4 * tol
     if it >= 3 and rmax_prev < 1e-3 and since_rr + 1 < opt["rr_every"] and not near_done: do_rr = False
     if do_rr:
@@ -58,7 +58,7 @@ for it in range(opt["maxit"]):
     else:
         since_rr += 1; A = Q; B = Z; rmax_prev *= rate
     if theta is None:   # no Rayleigh-Ritz yet: a-priori bounds
-        top = np.abs(G).sum(0).max(); cut = trace_mean; m = 5; c = e = 0.5 * cut; sigma1 = e / (top - c)
+        top = np.abs(G).sum(0).max(); cut = trace_mean; m = opt['m0'] if it == 0 else opt['m1']; c = e = 0.5 * cut; sigma1 = e / (top - c)
     else:
         top = max(theta[0], 1e-300)
         cut_pos = Kact + (ba - Kact) * opt["cut_pct"] // 100

@@ -109,3 +109,13 @@ def test_r_shim_type_checks_and_registers_the_reference_symbols():
               "_FLGP_local_anchor_embedding_cpp": 2, "_FLGP_v_to_z_cpp": 1}
     got = {m.group(1): int(m.group(2)) for m in re.finditer(r'\{"(_FLGP_\w+)",\s*\(DL_FUNC\)&\w+,\s*(\d+)\}', text)}
     assert got == expect
+
+
+def test_header_states_the_eig_info_contract():
+    """flgp_dev_eig_topk writes FOUR ints of `info` (round-1 advisor: the header promised two and a C caller with
+    int info[2] got its stack overwritten)."""
+    text = open(os.path.join(ROOT, "include", "flgp_hip.h")).read()
+    doc = text[text.index("size_t flgp_dev_eig_workspace") - 900:text.index("size_t flgp_dev_eig_workspace")]
+    assert "FOUR ints" in doc and "[3]" in doc
+    src = open(os.path.join(ROOT, "flgp_amd", "csrc", "eig.hip")).read()
+    assert "info[4]" not in src and "info[3]" in src

@@ -129,6 +129,49 @@ def test_knn_errors():
     assert e.value.code == -1 and "<= 64" in e.value.message
 
 
+def test_bad_inputs_are_refused_not_faulted(oracle):
+    """Round-1 advisor findings: a NaN / Inf coordinate (R's NA_real_ is a NaN) left the k-NN list's 0x7fffffff
+    sentinel in ind_knn, which LAE / CSC / Gram then used as an address; user-supplied CSR column indices reached the
+    same kernels unchecked; a zero singular value put Inf / NaN into every entry of H.  All three are errors now."""
+    import scipy.sparse as sp
+    X, U0, U = make_case(300, 3, 40, 4, seed=11)
+    for bad in (np.nan, np.inf, -np.inf):
+        Xb = X.copy(); Xb[17, 1] = bad
+        with pytest.raises(api.FlgpError) as e:
+            api.KNN_cpp(Xb, U0, 4)
+        assert e.value.code == -1 and "NaN" in e.value.message
+        with pytest.raises(api.FlgpError):
+            api.heat_kernel_covariance_rcpp(Xb[:20], Xb[20:], 40, 4, 1.0, K=10, U=U)
+    Ub = U0.copy(); Ub[3, 0] = np.nan
+    with pytest.raises(api.FlgpError):
+        api.LAE_cpp(X, Ub, 4)
+    # the device entry point cannot refuse (asynchronous): it must at least hand out valid indices
+    st = HipStages("cuda:0")
+    Xb = X.copy(); Xb[5, :] = np.nan
+    idx, _ = st.knn(cm(Xb), st.anchor_prep(cm(U0)), 4)
+    idx = idx.cpu().numpy()
+    assert idx.min() >= 0 and idx.max() < 40
+    np.testing.assert_array_equal(np.delete(idx, 5, axis=1), np.delete(oracle.knn(X, U0, 4).T, 5, axis=1))
+    # CSR column index out of range
+    Z = api.LAE_cpp(X, U0, 4)
+    Zb = sp.csr_matrix((Z.data.copy(), Z.indices.copy(), Z.indptr.copy()), shape=Z.shape)
+    Zb.indices[123] = 40
+    with pytest.raises(api.FlgpError) as e:
+        api.graphLaplacian_cpp(Zb, "normalized")
+    assert "outside" in e.value.message
+    Zb.indices[123] = -1
+    with pytest.raises(api.FlgpError):
+        api.spectrum_from_Z_cpp(Zb, 5)
+    # K == s with an anchor column that is exactly zero: sigma_s = 0
+    Zz = sp.csr_matrix((Z.data.copy(), Z.indices.copy(), Z.indptr.copy()), shape=Z.shape)
+    Zz.data[Zz.indices == 7] = 0.0
+    with pytest.raises(api.FlgpError) as e:
+        api.spectrum_from_Z_cpp(Zz, -1)
+    assert e.value.code == -5 and "null space" in e.value.message
+    ep = api.spectrum_from_Z_cpp(Zz, 10)                  # a smaller K is fine
+    assert np.isfinite(ep.vectors).all()
+
+
 # ------------------------------------------------------------------------------ LAE (k3+k4)
 def test_v_to_z(oracle):
     ka = np.load(os.path.join(GOLDEN, "known_answers.npz"))
