@@ -659,6 +659,21 @@ __global__ void permute_scale_kernel(const double *__restrict__ V, int ldv, int 
   W[(size_t)j * ldw + i] = v;
 }
 
+// Ritz values in descending order without the host: perm[rank] = j, sorted[rank] = lam[j], rank = number of values
+// ahead of lam[j] (larger, or equal with a lower index: the order std::stable_sort gives)
+__global__ void ritz_sort_kernel(const double *__restrict__ lam, int b, int *__restrict__ perm, double *__restrict__ sorted) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= b) return;
+  const double mine = lam[j];
+  int rank = 0;
+  for (int i = 0; i < b; ++i) {
+    const double v = lam[i];
+    rank += (v > mine) || (v == mine && i < j);
+  }
+  perm[rank] = j;
+  sorted[rank] = mine;
+}
+
 // S <- D S D with D = diag(1/sqrt(S_jj)): the Gram matrix of the column-normalised block
 __global__ void sym_scale_diag_kernel(const double *__restrict__ S, int b, double *__restrict__ dinv) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
@@ -793,7 +808,7 @@ struct EigWork {
   double *Q, *Y, *Yp, *Z, *Qold;
   // small (b x b)
   double *T, *JB, *JV, *W, *X2, *Id;
-  double *lam, *scale, *res, *dinv, *gemm_ws, *apriori;
+  double *lam, *scale, *res, *theta, *dinv, *gemm_ws, *apriori;   // res (b) and theta (b) are adjacent: one copy to the host
   int *perm, *flags;
   int *tickets;         // GEMM_MAX_TICKETS zeroed counters of the in-kernel split-K reduction (main stream only)
   size_t gemm_ws_elems;
@@ -854,7 +869,7 @@ static size_t eig_workspace_bytes(int s, int K) {
   size_t tot = 0;
   if (!dense) tot += 5 * align_up(sizeof(double) * (size_t)s * b);
   tot += 6 * align_up(sizeof(double) * (size_t)b * b);
-  tot += 4 * align_up(sizeof(double) * (size_t)b) + align_up(sizeof(double) * 2 * APRIORI_BLOCKS);
+  tot += 5 * align_up(sizeof(double) * (size_t)b) + align_up(sizeof(double) * 2 * APRIORI_BLOCKS);
   tot += align_up(sizeof(int) * (size_t)b) + align_up(sizeof(int) * 16) + align_up(sizeof(int) * GEMM_MAX_TICKETS);
   if (!dense) tot += align_up(sizeof(double) * eig_gemm_ws_elems(s, b));
   if (!dense && s >= 1024) tot += bsg_workspace_bytes(s, b);   // (used from s = 1536 on by default; tunable)
@@ -869,7 +884,8 @@ static size_t eig_workspace_bytes(int s, int K) {
 // sweep_limit = k > 0: exactly k sweeps, a refinement step on an already nearly diagonal T.
 // JV is a product of plane rotations, i.e. orthogonal to rounding, however early the loop stops.
 static int jacobi_run(hipStream_t st, int b, EigWork &w, std::vector<double> &h_lam, int *sweeps_out,
-                      int sweep_limit, double tol_scale, bool strict, double *JB = nullptr, double *JV = nullptr) {
+                      int sweep_limit, double tol_scale, bool strict, double *JB = nullptr, double *JV = nullptr,
+                      bool to_host = true) {
   if (!JB) JB = w.JB;
   if (!JV) JV = w.JV;
   const JacobiPlan p = jacobi_plan(b);
@@ -908,6 +924,7 @@ static int jacobi_run(hipStream_t st, int b, EigWork &w, std::vector<double> &h_
   }
   hipLaunchKernelGGL(jac_values_kernel, dim3(b), dim3(256), 0, st, JB, JV, b, b, w.lam);
   FLGP_TRY(check_launch("jac_values_kernel"));
+  if (!to_host) return FLGP_OK;        // a fixed number of sweeps on the device: the eigenvalues stay in w.lam
   h_lam.resize(b);
   FLGP_HIP(hipMemcpyAsync(h_lam.data(), w.lam, sizeof(double) * b, hipMemcpyDeviceToHost, st));
   FLGP_HIP(hipMemcpyAsync(h_flags, w.flags, sizeof(int) * 3, hipMemcpyDeviceToHost, st));
@@ -923,12 +940,13 @@ static int jacobi_run(hipStream_t st, int b, EigWork &w, std::vector<double> &h_
 // symmetric eigendecomposition of the b x b matrix T (device): on return JV holds eigenvectors,
 // h_lam the eigenvalues (unsorted, host copy).  Synchronises the stream.
 static int jacobi_eig(hipStream_t st, const double *T, int ldt, int b, EigWork &w, std::vector<double> &h_lam,
-                      int *sweeps_out, int sweep_limit = -1, double tol_scale = 1.0, bool strict = false) {
+                      int *sweeps_out, int sweep_limit = -1, double tol_scale = 1.0, bool strict = false,
+                      bool to_host = true) {
   ProfScope ps("jacobi_eig", st, 8.0 * (double)b * b);
   hipLaunchKernelGGL(jac_init_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, T, ldt, b, w.JB, w.JV, b,
                      w.flags);
   FLGP_TRY(check_launch("jac_init_kernel"));
-  return jacobi_run(st, b, w, h_lam, sweeps_out, sweep_limit, tol_scale, strict);
+  return jacobi_run(st, b, w, h_lam, sweeps_out, sweep_limit, tol_scale, strict, nullptr, nullptr, to_host || sweep_limit < 0);
 }
 
 // Rayleigh-Ritz refinement for a T that is diagonal up to small couplings EXCEPT in its trailing
@@ -937,7 +955,7 @@ static int jacobi_eig(hipStream_t st, const double *T, int ldt, int b, EigWork &
 //   2. with V0 = blockdiag(I, Vg), B0 = T V0, `sweeps` global sweeps finish the job
 //      (quadratic convergence: couplings eps -> eps^2 per sweep).
 static int jacobi_refine(hipStream_t st, const double *T, int b, int K, EigWork &w, std::vector<double> &h_lam,
-                         int *sweeps_out, int sweeps) {
+                         int *sweeps_out, int sweeps, bool to_host = true) {
   const int g = b - K;
   if (g < 2 || 2 * (size_t)g * g > (size_t)b * b)
     return jacobi_eig(st, T, b, b, w, h_lam, sweeps_out, -1, 1.0);
@@ -959,7 +977,7 @@ static int jacobi_refine(hipStream_t st, const double *T, int b, int K, EigWork 
                        Bg, Vg, g, w.flags);
     FLGP_TRY(check_launch("jac_init_kernel"));
     std::vector<double> tmp;
-    FLGP_TRY(jacobi_run(st, g, w, tmp, nullptr, 4, 1.0, false, Bg, Vg));
+    FLGP_TRY(jacobi_run(st, g, w, tmp, nullptr, 4, 1.0, false, Bg, Vg, false));
   }
   hipLaunchKernelGGL(embed_block_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, Vg, g, K, b, w.JV);
   FLGP_TRY(check_launch("embed_block_kernel"));
@@ -974,7 +992,15 @@ static int jacobi_refine(hipStream_t st, const double *T, int b, int K, EigWork 
     FLGP_TRY(gemm_launch(st, b, b, b, 1.0, T, 1, b, w.JV, 1, b, 0.0, nullptr, 0, 0, w.JB, 1, b, w.gemm_ws, w.gemm_ws_elems,
                          0.0, nullptr));
   }
-  return jacobi_run(st, b, w, h_lam, sweeps_out, sweeps, 1.0, false);
+  return jacobi_run(st, b, w, h_lam, sweeps_out, sweeps, 1.0, false, nullptr, nullptr, to_host);
+}
+
+// W = JV(:, order), order = the eigenvalues in w.lam descending, all on the device: w.perm = order, w.theta = sorted values
+static int sorted_basis_dev(hipStream_t st, int b, EigWork &w) {
+  hipLaunchKernelGGL(ritz_sort_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, st, w.lam, b, w.perm, w.theta);
+  hipLaunchKernelGGL(permute_scale_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, w.JV, b, b, w.perm,
+                     (const double *)nullptr, (const double *)nullptr, b, w.W, b);
+  return check_launch("ritz_sort_kernel");
 }
 
 // W = JV(:, order) * diag(scale), order = eigenvalues descending
@@ -1028,7 +1054,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   w.T = (double *)take(small); w.JB = (double *)take(small); w.JV = (double *)take(small); w.W = (double *)take(small);
   w.X2 = (double *)take(small); w.Id = (double *)take(small);
   w.lam = (double *)take(sizeof(double) * b); w.scale = (double *)take(sizeof(double) * b);
-  w.res = (double *)take(sizeof(double) * b); w.dinv = (double *)take(sizeof(double) * b);
+  w.res = (double *)take(sizeof(double) * 2 * b); w.theta = w.res + b; w.dinv = (double *)take(sizeof(double) * b);
   w.apriori = (double *)take(sizeof(double) * 2 * APRIORI_BLOCKS);
   w.perm = (int *)take(sizeof(int) * b); w.flags = (int *)take(sizeof(int) * 16);
   w.tickets = (int *)take(sizeof(int) * GEMM_MAX_TICKETS);
@@ -1151,7 +1177,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
       // iterations without talking to the host, then check once (|I - S|_F over-estimates e, so
       // the prediction errs on the safe side); a block that does not contract falls through to Jacobi
       int kmax = 2;
-      for (double e = std::min(delta, 0.95); e > 1e-17 && kmax < 40; ++kmax) e = (e < 0.5) ? 0.8 * e * e : 0.5 * e + 0.4 * e * e;
+      for (double e = std::min(delta * 0.01 * tuning("eig_ns_e0_pct", 100), 0.95); e > 1e-17 && kmax < 40; ++kmax) e = (e < 0.5) ? 0.8 * e * e : 0.5 * e + 0.4 * e * e;
       bool ok = false;
       for (int k = 0; k < kmax; ++k) {
         FLGP_TRY(small_gemm(Zc, Yc, -0.5, 1.5, w.Id, Mm));
@@ -1369,15 +1395,17 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     *spare_out = prev;
     return FLGP_OK;
   };
-  // residuals of the K wanted pairs (A = Ritz vectors, B = G A); synchronises `st`
+  // residuals of the K wanted pairs (A = Ritz vectors, B = G A) with the Ritz values sorted_basis_dev left in w.theta;
+  // the ONE host round trip of a Rayleigh-Ritz step: brings the residuals and the sorted Ritz values over together
+  std::vector<double> rt(2 * (size_t)b);
   auto residuals = [&](const double *A, const double *B, double *rmax_out) -> int {
-    FLGP_HIP(hipMemcpyAsync(w.lam, theta.data(), sizeof(double) * b, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(resid_kernel, dim3(K), dim3(256), 0, st, B, A, s, s, w.lam, w.res);
+    hipLaunchKernelGGL(resid_kernel, dim3(K), dim3(256), 0, st, B, A, s, s, w.theta, w.res);
     FLGP_TRY(check_launch("resid_kernel"));
-    FLGP_HIP(hipMemcpyAsync(res.data(), w.res, sizeof(double) * K, hipMemcpyDeviceToHost, st));
+    FLGP_HIP(hipMemcpyAsync(rt.data(), w.res, sizeof(double) * 2 * b, hipMemcpyDeviceToHost, st));
     FLGP_HIP(stream_wait(st));
     double rmax = 0.0;
-    for (int j = 0; j < K; ++j) rmax = std::max(rmax, res[j]);
+    for (int j = 0; j < K; ++j) { res[j] = rt[j]; rmax = std::max(rmax, res[j]); }
+    for (int j = 0; j < b; ++j) theta[j] = rt[b + j];
     *rmax_out = rmax;
     return FLGP_OK;
   };
@@ -1438,10 +1466,14 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
       FLGP_TRY(apply_filter(fp, Q, Z, F[1], F[2], &cur, &spare));
       // the other stream: T = W Th W^T
       FLGP_HIP(hipStreamWaitEvent(side.st, side.ev, 0));
-      FLGP_TRY(jacobi_refine(side.st, w.T, b, K, w, lam, &sweeps,
-                             std::max(1, (rmax_prev > 1e-4 * tuning("eig_refine3_above_e4", 2000) ? 3 : (rmax_prev > 1e-8 * tuning("eig_refine2_above_e8", 100) ? 2 : 1)) - tuning("eig_refine_minus", 0))));
-      FLGP_TRY(sorted_basis(side.st, lam, nullptr, b, b, w, order));   // synchronises the side stream: W is ready
-      for (int j = 0; j < b; ++j) theta[j] = lam[order[j]];
+      {
+        const int nsw = std::max(1, (rmax_prev > 1e-4 * tuning("eig_refine3_above_e4", 2000) ? 3 : (rmax_prev > 1e-8 * tuning("eig_refine2_above_e8", 100) ? 2 : 1)) - tuning("eig_refine_minus", 0));
+        FLGP_TRY(jacobi_refine(side.st, w.T, b, K, w, lam, &sweeps, nsw, false));
+        sweeps = nsw;
+      }
+      FLGP_TRY(sorted_basis_dev(side.st, b, w));       // order and W on the device: the host is not asked
+      FLGP_HIP(hipEventRecord(side.ev, side.st));
+      FLGP_HIP(hipStreamWaitEvent(st, side.ev, 0));
       // the two buffers of {Q, F1, F2} that do not hold the filtered block take A and B
       double *trio[3] = {Q, F[1], F[2]};
       double *x[2]; int nx = 0;
@@ -1468,15 +1500,17 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
         // (a fixed small number of global sweeps alone is NOT enough, even late: the guard columns
         //  never converge, so their diagonal block of T stays dense -- measured: 2 sweeps put rmax
         //  back to 4e-2.  jacobi_refine diagonalises that block first.)
-        if (it < 2)         // bounds and a rough Ritz basis are all that is needed yet: loose threshold, capped sweeps
-          FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps, tuning(it == 0 ? "eig_sweeps_it0" : "eig_sweeps_it1", 2), 1e10));
-        else if (rmax_prev > 5e-2)
-          FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, &sweeps, tuning("eig_sweeps_it2", 2), 1e6));
-        else
-          FLGP_TRY(jacobi_refine(st, w.T, b, K, w, lam, &sweeps,
-                                 std::max(1, (rmax_prev > 1e-4 * tuning("eig_refine3_above_e4", 2000) ? 3 : (rmax_prev > 1e-8 * tuning("eig_refine2_above_e8", 100) ? 2 : 1)) - tuning("eig_refine_minus", 0))));
-        FLGP_TRY(sorted_basis(st, lam, nullptr, b, b, w, order));
-        for (int j = 0; j < b; ++j) theta[j] = lam[order[j]];
+        if (it < 2) {       // bounds and a rough Ritz basis are all that is needed yet: loose threshold, capped sweeps
+          sweeps = tuning(it == 0 ? "eig_sweeps_it0" : "eig_sweeps_it1", 2);
+          FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, nullptr, sweeps, 1e10, false, false));
+        } else if (rmax_prev > 5e-2) {
+          sweeps = tuning("eig_sweeps_it2", 2);
+          FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, nullptr, sweeps, 1e6, false, false));
+        } else {
+          sweeps = std::max(1, (rmax_prev > 1e-4 * tuning("eig_refine3_above_e4", 2000) ? 3 : (rmax_prev > 1e-8 * tuning("eig_refine2_above_e8", 100) ? 2 : 1)) - tuning("eig_refine_minus", 0));
+          FLGP_TRY(jacobi_refine(st, w.T, b, K, w, lam, nullptr, sweeps, false));
+        }
+        FLGP_TRY(sorted_basis_dev(st, b, w));
         FLGP_TRY(rotate(Q, w.W, A));   // A = Ritz vectors
         FLGP_TRY(rotate(Z, w.W, B));   // B = G * Ritz vectors
         FLGP_TRY(residuals(A, B, &rmax));
