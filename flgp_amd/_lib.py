@@ -73,7 +73,8 @@ _SIGNATURES = {
     "flgp_dev_se_weights": (c_int, [P, P, P, c_int, c_int, c_int, c_double, P, P]),
     "flgp_dev_csc_workspace": (c_size_t, [c_int, c_int, c_int]),
     "flgp_dev_csc_build": (c_int, [P, P, c_int, c_int, c_int, P, P, P, c_size_t]),
-    "flgp_dev_colsum": (c_int, [P, P, P, P, c_int, P]),
+    "flgp_dev_colsum_workspace": (c_size_t, [c_int, c_int]),
+    "flgp_dev_colsum": (c_int, [P, P, P, c_int, c_int, c_int, P, P, c_size_t]),
     "flgp_dev_col_scale": (c_int, [P, P, P, c_int, c_int, P, P, c_int]),
     "flgp_dev_row_normalize": (c_int, [P, P, c_int, c_int]),
     "flgp_dev_gram": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, c_int]),

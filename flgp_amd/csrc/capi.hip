@@ -88,7 +88,7 @@ int d2h(void *dst, const void *src, size_t bytes, hipStream_t st) {
 
 // device-side state of one similarity matrix: anchors, k-NN, ELL (+ CSC view)
 struct Sim {
-  DevBuf X, U, Ut, uu, knn_idx, knn_dist, ell_idx, ell_val, colptr, pos, colsum, work, num_class;
+  DevBuf X, U, Ut, uu, knn_idx, knn_dist, ell_idx, ell_val, colptr, pos, colsum, cswork, work, num_class;
   int n = 0, d = 0, s = 0, r = 0;
   bool have_csc = false;
 };
@@ -134,13 +134,20 @@ int alloc_ell(Sim &S) {
   return S.ell_val.alloc(sizeof(double) * (size_t)S.n * S.r);
 }
 
+// column sums of the device ELL into S.colsum (two-level order of the oracle)
+int colsum_of(Sim &S, hipStream_t st, const int *d_idx, const double *d_val) {
+  const size_t wb = flgp_dev_colsum_workspace(S.n, S.s);
+  if (!S.colsum.p) FLGP_TRY(S.colsum.alloc(sizeof(double) * (size_t)S.s));
+  if (!S.cswork.p) FLGP_TRY(S.cswork.alloc(wb));
+  return flgp_dev_colsum(st, d_idx, d_val, S.n, S.r, S.s, S.colsum.as<double>(), S.cswork.p, wb);
+}
+
 int build_csc(Sim &S, hipStream_t st) {
   if (S.have_csc) return FLGP_OK;
   const size_t wb = flgp_dev_csc_workspace(S.n, S.s, S.r);
   FLGP_TRY(S.work.alloc(wb));
   FLGP_TRY(S.colptr.alloc(sizeof(int) * (size_t)(S.s + 1)));
   FLGP_TRY(S.pos.alloc(sizeof(int) * (size_t)S.n * S.r));
-  FLGP_TRY(S.colsum.alloc(sizeof(double) * (size_t)S.s));
   FLGP_TRY(flgp_dev_csc_build(st, S.ell_idx.as<int>(), S.n, S.s, S.r, S.colptr.as<int>(), S.pos.as<int>(), S.work.p, wb));
   S.have_csc = true;
   return FLGP_OK;
@@ -149,8 +156,7 @@ int build_csc(Sim &S, hipStream_t st) {
 // graphLaplacian_cpp on the device ELL (reference src/Utils.cpp:195-212)
 int laplacian(Sim &S, hipStream_t st, int gl, const double *d_num_class) {
   if (gl != FLGP_GL_RW) {
-    FLGP_TRY(build_csc(S, st));
-    FLGP_TRY(flgp_dev_colsum(st, S.ell_val.as<double>(), S.colptr.as<int>(), S.pos.as<int>(), S.s, S.colsum.as<double>()));
+    FLGP_TRY(colsum_of(S, st, S.ell_idx.as<int>(), S.ell_val.as<double>()));
     FLGP_TRY(flgp_dev_col_scale(st, S.ell_idx.as<int>(), S.ell_val.as<double>(), S.n, S.r, S.colsum.as<double>(),
                                 gl == FLGP_GL_CLUSTER_NORMALIZED ? d_num_class : nullptr, 0));
   }
@@ -194,7 +200,7 @@ int spectrum(Sim &S, hipStream_t st, int K, int root, Spectrum &P, int *info) {
   P.K = K;
   FLGP_TRY(build_csc(S, st));
   // A = Z diag(1/sqrt(|colsum|+1e-9))  (:149-150)
-  FLGP_TRY(flgp_dev_colsum(st, S.ell_val.as<double>(), S.colptr.as<int>(), S.pos.as<int>(), S.s, S.colsum.as<double>()));
+  FLGP_TRY(colsum_of(S, st, S.ell_idx.as<int>(), S.ell_val.as<double>()));
   FLGP_TRY(flgp_dev_col_scale(st, S.ell_idx.as<int>(), S.ell_val.as<double>(), S.n, S.r, S.colsum.as<double>(), nullptr, 1));
   // Gram + top-K eigenpairs (replaces RSpectra::svds / BDCSVD, src/TruncatedSVD.cpp:17-30)
   FLGP_TRY(P.G.alloc(sizeof(double) * (size_t)S.s * S.s));
@@ -788,7 +794,6 @@ extern "C" int flgp_se_spectrum_grid(const double *X_all, int n, int d, const do
     Sim W;   // shares pattern / CSC with S, owns its values
     W.n = n; W.d = d; W.s = s; W.r = r;
     FLGP_TRY(W.ell_val.alloc(sizeof(double) * (size_t)n * r));
-    FLGP_TRY(W.colsum.alloc(sizeof(double) * (size_t)s));
     DevBuf scratch_idx;
     FLGP_TRY(scratch_idx.alloc(sizeof(int) * (size_t)n * r));
     FLGP_TRY(flgp_dev_se_weights_den(ws.s, S.knn_idx.as<int>(), S.knn_dist.as<double>(), n, n, r, a2s[i] * mean,
@@ -796,12 +801,12 @@ extern "C" int flgp_se_spectrum_grid(const double *X_all, int n, int d, const do
     const int *eidx = S.ell_idx.as<int>();
     const int *colptr = S.colptr.as<int>(), *pos = S.pos.as<int>();
     if (glc != FLGP_GL_RW) {
-      FLGP_TRY(flgp_dev_colsum(ws.s, W.ell_val.as<double>(), colptr, pos, s, W.colsum.as<double>()));
+      FLGP_TRY(colsum_of(W, ws.s, eidx, W.ell_val.as<double>()));
       FLGP_TRY(flgp_dev_col_scale(ws.s, eidx, W.ell_val.as<double>(), n, r, W.colsum.as<double>(),
                                   glc == FLGP_GL_CLUSTER_NORMALIZED ? sizes : nullptr, 0));
     }
     FLGP_TRY(flgp_dev_row_normalize(ws.s, W.ell_val.as<double>(), n, r));
-    FLGP_TRY(flgp_dev_colsum(ws.s, W.ell_val.as<double>(), colptr, pos, s, W.colsum.as<double>()));
+    FLGP_TRY(colsum_of(W, ws.s, eidx, W.ell_val.as<double>()));
     FLGP_TRY(flgp_dev_col_scale(ws.s, eidx, W.ell_val.as<double>(), n, r, W.colsum.as<double>(), nullptr, 1));
     DevBuf G, eig, V, vals, vecs, ework, uwork;
     FLGP_TRY(G.alloc(sizeof(double) * (size_t)s * s));

@@ -114,31 +114,68 @@ __global__ __launch_bounds__(64) void csc_scatter_kernel(const int *__restrict__
   }
 }
 
-// colsum[j] = sum over the column's entries in ascending row order, strictly sequential adds from
-// 0.0 (the oracle's / the reference's order).  One wave per column: the 64 lanes fetch the next 64
-// entries in parallel (that is where the time goes: two dependent gathers per entry), then the
-// values are added one after the other in entry order.
-__global__ __launch_bounds__(64) void colsum_kernel(const double *__restrict__ val, const int *__restrict__ colptr,
-                                                    const int *__restrict__ pos, int s, double *__restrict__ colsum) {
-  const int j = blockIdx.x;
-  if (j >= s) return;
+// Column sums in the fixed two-level order of the oracle (oracle/flgp_oracle.c, flgp_oracle_colsum): chunks of
+// COLSUM_CHUNK consecutive rows; inside a chunk every column's entries are added in row order, then the chunk totals
+// in chunk order.  One wave owns a chunk and a table of s sums in LDS, streams the chunk's entries 64 at a time
+// (coalesced: the round-1 kernel walked the CSC lists instead and fetched a 128-byte line for every 8-byte value,
+// 1.2 GB for 80 MB) and adds them with ds_add_f64.  Lanes of one step that hit the same column are ranked by lane
+// (= entry order) with the ballot match of csc_scatter_kernel and applied in as many passes as the largest rank
+// needs; the LDS unit executes a wave's instructions in order, so pass k+1 sees pass k.
+constexpr int COLSUM_CHUNK = 1024;     // rows; FLGP_COLSUM_CHUNK of the oracle
+
+__global__ __launch_bounds__(64) void colsum_chunk_kernel(const int *__restrict__ ell_idx, const double *__restrict__ val,
+                                                          int n, int r, int s, int nbits, double *__restrict__ part) {
+  extern __shared__ double bins[];
   const int lane = threadIdx.x;
-  const int p0 = colptr[j], p1 = colptr[j + 1];
-  double acc = 0.0;
-  // the next 64 entries are gathered (two dependent loads) while the current 64 are added
-  double v = (p0 + lane < p1) ? val[pos[p0 + lane]] : 0.0;
-  for (int pb = p0; pb < p1; pb += 64) {
-    const int pn = pb + 64 + lane;
-    const double vn = (pn < p1) ? val[pos[pn]] : 0.0;
-    const int cnt = (p1 - pb < 64) ? p1 - pb : 64;
-    // lane l's value through v_readlane (l is wave-uniform): a ds_bpermute round trip per entry made this
-    // strictly sequential chain ~150 cycles a step
-    const int vlo = __double2loint(v), vhi = __double2hiint(v);
-    for (int l = 0; l < cnt; ++l)
-      acc += __hiloint2double(__builtin_amdgcn_readlane(vhi, l), __builtin_amdgcn_readlane(vlo, l));
-    v = vn;
+  for (int j = lane; j < s; j += 64) bins[j] = 0.0;
+  __syncthreads();
+  const long i0 = (long)blockIdx.x * COLSUM_CHUNK;
+  const long i1 = (i0 + COLSUM_CHUNK < n) ? i0 + COLSUM_CHUNK : n;
+  const long e0 = i0 * r, e1 = i1 * r;
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  // the next step's entries are loaded while this step's are ranked and added
+  long e = e0 + lane;
+  int col = (e < e1) ? ell_idx[e] : 0;
+  double v = (e < e1) ? val[e] : 0.0;
+  for (long eb = e0; eb < e1; eb += 64) {
+    const long en = eb + 64 + lane;
+    const int coln = (en < e1) ? ell_idx[en] : 0;
+    const double vn = (en < e1) ? val[en] : 0.0;
+    const bool act = eb + lane < e1;
+    unsigned long long m = __ballot(act);
+    for (int b = 0; b < nbits; ++b) {
+      const bool bit = (col >> b) & 1;
+      const unsigned long long bal = __ballot(bit);
+      m &= bit ? bal : ~bal;
+    }
+    const int rank = act ? __popcll(m & lt) : 0;
+    int maxrank = rank;
+    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(maxrank, off, 64); maxrank = o > maxrank ? o : maxrank; }
+    for (int k = 0; k <= maxrank; ++k)
+      if (act && rank == k)
+        __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)&bins[col], v);
+    col = coln; v = vn;
   }
-  if (lane == 0) colsum[j] = acc;
+  __syncthreads();
+  double *out = part + (size_t)blockIdx.x * s;
+  for (int j = lane; j < s; j += 64) out[j] = bins[j];
+}
+
+// colsum[j] = chunk totals added in chunk order, from 0.0
+__global__ void colsum_reduce_kernel(const double *__restrict__ part, int nchunks, int s, double *__restrict__ colsum) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= s) return;
+  double acc = 0.0;
+  int c = 0;
+  for (; c + 8 <= nchunks; c += 8) {      // eight loads in flight, added in order
+    double p[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) p[u] = part[(size_t)(c + u) * s + j];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc += p[u];
+  }
+  for (; c < nchunks; ++c) acc += part[(size_t)c * s + j];
+  colsum[j] = acc;
 }
 
 __global__ void col_scale_kernel(const int *__restrict__ ell_idx, double *__restrict__ val, long nnz,
@@ -181,55 +218,78 @@ __global__ __launch_bounds__(256) void row_normalize_kernel(double *__restrict__
 }
 
 // ----------------------------------------------------------------------------------------
-// Gram: one wave per column j1.  The wave owns row j1 of G in LDS (s doubles), walks the
-// column's entries in ascending row order, loads GR = 64/r rows of A at a time (memory-level
-// parallelism) and applies them to the LDS row one row after the other, so that every
-// G(j1, j2) is summed in ascending row order: deterministic, and identical to the oracle.
-// Bound (measured at n = 1e6, s = 5000, r = 10: 2.4 ms): the LDS f64 atomics themselves, ~150 cycles per ds_add_f64
-// instruction per CU -- neither two groups of six steps in flight nor line-aligned packed row records (3.4 -> 1.3 GB
-// fetched) moved the time, so the loads are not what it waits for.
+// Gram: one wave per column j1.  The wave owns row j1 of G in LDS (s doubles) and walks the column's entries in
+// ascending row order: every G(j1, j2) is summed in ascending row order -- deterministic, and identical to the oracle.
+// A row's r products go to r distinct bins, so one ds_add_f64 serves a whole row; consecutive rows of a column share
+// anchors (they all have j1, and usually more), so rows are applied one instruction after the other -- the LDS unit
+// executes a wave's instructions in order, which keeps the sums sequential without a round trip through registers.
+//
+// Where the time goes (round 2, scripts/ubench_ldsatomic.hip): a ds_add_f64 costs ~60 cycles per instruction per
+// wave whatever the number of active lanes, and four waves per CU get four times that throughput -- 2000 rows per
+// column, 5000 columns, 1024 resident waves: 0.25 ms.  The round-1 kernel took 2.4 ms because each step of six rows
+// first chased pos -> entry -> row (an integer division and two dependent gathers) with a single step of look-ahead.
+// Here LPR lanes serve a row (64 / LPR rows per group), the loads of GRAM_PF groups are in flight while the previous
+// GRAM_PF groups are applied, the next 64 positions are fetched a block ahead, and entry / r is a multiplication.
 // ----------------------------------------------------------------------------------------
+constexpr int GRAM_PF = 4;      // groups of rows whose loads are in flight together
+
+template <int LPR>
 __global__ __launch_bounds__(64) void gram_kernel(const int *__restrict__ ell_idx, const double *__restrict__ val,
-                                                  int s, int r, const int *__restrict__ colptr,
+                                                  int s, int r, double inv_r, const int *__restrict__ colptr,
                                                   const int *__restrict__ pos, double *__restrict__ G, int ldg) {
   extern __shared__ double acc[];
+  constexpr int RPG = 64 / LPR;     // rows per group
+  constexpr int NG = 64 / RPG;      // groups per block of 64 positions
   const int lane = threadIdx.x;
   const int j1 = blockIdx.x;
   for (int j = lane; j < s; j += 64) acc[j] = 0.0;
   __syncthreads();
-  const int GR = 64 / r;            // rows per step
-  const int sub = lane / r;         // which of the GR rows this lane serves
-  const int a = lane - sub * r;     // slot inside the row
+  const int sub = lane / LPR;       // which row of a group this lane serves
+  const int a = lane % LPR;         // slot inside the row
+  const bool slot_ok = a < r;
+  const int ac = slot_ok ? a : 0;
   const int p0 = colptr[j1], p1 = colptr[j1 + 1];
-  // entry positions are fetched 64 at a time (one coalesced load), the rows of a step one step ahead of
-  // the LDS updates: the chain pos -> val/idx -> LDS is otherwise pure exposed latency
+  int epos = (p0 + lane < p1) ? pos[p0 + lane] : 0;
   for (int pc = p0; pc < p1; pc += 64) {
-    const int epos = (pc + lane < p1) ? pos[pc + lane] : 0;
+    const int pn = pc + 64 + lane;
+    const int epos_next = (pn < p1) ? pos[pn] : 0;                 // a block ahead
     const int cnt = (p1 - pc < 64) ? p1 - pc : 64;
-    auto fetch = [&](int t, bool &act, int &j2, double &prod) {
-      const int slot = t * GR + sub;
-      act = (sub < GR) && (slot < cnt) && (t * GR < cnt);
-      const int e = __shfl(epos, (slot < 64) ? slot : 0, 64);
-      j2 = 0; prod = 0.0;
-      if (act) {
-        const size_t rowbase = (size_t)(e / r) * r;
-        j2 = ell_idx[rowbase + a];
-        prod = val[e] * val[rowbase + a];
-      }
+    struct Grp { int j2; double v, vj; bool act; };
+    // loads are unconditional (inactive slots read entry 0 of row 0: a valid address), so that the number in flight
+    // does not depend on the path and the compiler's wait counts stay tight
+    auto fetch = [&](int g) {
+      Grp o;
+      const int slot = g * RPG + sub;
+      o.act = slot_ok && slot < cnt;
+      const int e = __shfl(epos, slot & 63, 64);
+      const int ee = o.act ? e : 0;
+      const int row = (int)(((double)ee + 0.5) * inv_r);            // == ee / r exactly for ee < 2^31, r <= 32
+      const size_t rowbase = (size_t)row * r;
+      o.j2 = ell_idx[rowbase + ac];
+      o.v = val[rowbase + ac];
+      o.vj = val[ee];
+      return o;
     };
-    const int nsteps = (cnt + GR - 1) / GR;
-    bool act, actn; int j2, j2n; double prod, prodn;
-    fetch(0, act, j2, prod);
-    for (int t = 0; t < nsteps; ++t) {
-      fetch(t + 1, actn, j2n, prodn);          // t + 1 == nsteps: all lanes inactive
-      // rows strictly in order; distinct j2 inside a row.  One ds_add_f64 per row: the LDS unit executes a
-      // wave's instructions in order, so row q+1's additions see row q's sums without a round trip through
-      // registers and without a barrier (the read-add-write version spent ~600 cycles per row on latency)
-      for (int q = 0; q < GR; ++q)
-        if (act && sub == q)
-          __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)&acc[j2], prod);
-      act = actn; j2 = j2n; prod = prodn;
+    auto apply = [&](const Grp &o) {
+      const double prod = o.vj * o.v;
+#pragma unroll
+      for (int q = 0; q < RPG; ++q)
+        if (o.act && sub == q)
+          __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)&acc[o.j2], prod);
+    };
+    Grp cur[GRAM_PF], nxt[GRAM_PF];
+#pragma unroll
+    for (int u = 0; u < GRAM_PF; ++u) cur[u] = fetch(u);
+    for (int g0 = 0; g0 < NG; g0 += GRAM_PF) {
+      if (g0 * RPG >= cnt) break;                                   // uniform: the rest of the block is empty
+#pragma unroll
+      for (int u = 0; u < GRAM_PF; ++u) nxt[u] = fetch(g0 + GRAM_PF + u);   // (past the block: slot >= cnt, inactive)
+#pragma unroll
+      for (int u = 0; u < GRAM_PF; ++u) apply(cur[u]);
+#pragma unroll
+      for (int u = 0; u < GRAM_PF; ++u) cur[u] = nxt[u];
     }
+    epos = epos_next;
   }
   __syncthreads();
   double *out = G + (size_t)j1 * ldg;
@@ -399,12 +459,26 @@ extern "C" int flgp_dev_csc_build(void *stream, const int *d_ell_idx, int n, int
   return check_launch("csc_scatter_kernel");
 }
 
-extern "C" int flgp_dev_colsum(void *stream, const double *d_ell_val, const int *d_colptr, const int *d_pos,
-                               int s, double *d_colsum) {
-  ProfScope ps("colsum_kernel", (hipStream_t)stream, 0.0);
-  hipLaunchKernelGGL(colsum_kernel, dim3(s), dim3(64), 0, (hipStream_t)stream, d_ell_val, d_colptr,
-                     d_pos, s, d_colsum);
-  return check_launch("colsum_kernel");
+extern "C" size_t flgp_dev_colsum_workspace(int n, int s) {
+  return sizeof(double) * (size_t)ceil_div(n > 0 ? n : 1, COLSUM_CHUNK) * (size_t)s + 256;
+}
+
+extern "C" int flgp_dev_colsum(void *stream, const int *d_ell_idx, const double *d_ell_val, int n, int r, int s,
+                               double *d_colsum, void *d_work, size_t work_bytes) {
+  hipStream_t st = (hipStream_t)stream;
+  FLGP_REQUIRE(n >= 0 && r >= 1 && s >= 1 && s <= 20000, "colsum: kernels are built for s <= 20000 (got %d)", s);
+  FLGP_REQUIRE(work_bytes >= flgp_dev_colsum_workspace(n, s), "colsum: workspace too small");
+  const int nchunks = ceil_div(n > 0 ? n : 1, COLSUM_CHUNK);
+  int nbits = 1;
+  while ((1 << nbits) < s) ++nbits;
+  const size_t lds = sizeof(double) * (size_t)s;
+  if (lds > 48 * 1024)
+    FLGP_HIP(hipFuncSetAttribute((const void *)colsum_chunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  ProfScope ps("colsum_kernel", st, 12.0 * (double)n * r);
+  hipLaunchKernelGGL(colsum_chunk_kernel, dim3(nchunks), dim3(64), lds, st, d_ell_idx, d_ell_val, n, r, s, nbits, (double *)d_work);
+  FLGP_TRY(check_launch("colsum_chunk_kernel"));
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(ceil_div(s, 256)), dim3(256), 0, st, (const double *)d_work, nchunks, s, d_colsum);
+  return check_launch("colsum_reduce_kernel");
 }
 
 extern "C" int flgp_dev_col_scale(void *stream, const int *d_ell_idx, double *d_ell_val, int n, int r,
@@ -434,11 +508,15 @@ extern "C" int flgp_dev_gram(void *stream, const int *d_ell_idx, const double *d
   FLGP_REQUIRE(s >= 1 && s <= 20000, "Gram: kernel is built for s <= 20000 (got %d)", s);
   FLGP_REQUIRE(r >= 1 && r <= FLGP_RMAX && ldg >= s, "Gram: bad r / ldg");
   const size_t lds = sizeof(double) * (size_t)s;
-  if (lds > 48 * 1024)
-    FLGP_HIP(hipFuncSetAttribute((const void *)gram_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const void *fn = r <= 16 ? (const void *)gram_kernel<16> : (const void *)gram_kernel<32>;
+  if (lds > 48 * 1024) FLGP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   ProfScope ps("gram_kernel", (hipStream_t)stream, 12.0 * (double)n * r + 8.0 * (double)s * s);
-  hipLaunchKernelGGL(gram_kernel, dim3(s), dim3(64), lds, (hipStream_t)stream, d_ell_idx, d_ell_val, s, r, d_colptr,
-                     d_pos, dG, ldg);
+  if (r <= 16)
+    hipLaunchKernelGGL(gram_kernel<16>, dim3(s), dim3(64), lds, (hipStream_t)stream, d_ell_idx, d_ell_val, s, r, 1.0 / (double)r,
+                       d_colptr, d_pos, dG, ldg);
+  else
+    hipLaunchKernelGGL(gram_kernel<32>, dim3(s), dim3(64), lds, (hipStream_t)stream, d_ell_idx, d_ell_val, s, r, 1.0 / (double)r,
+                       d_colptr, d_pos, dG, ldg);
   return check_launch("gram_kernel");
 }
 

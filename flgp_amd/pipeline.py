@@ -100,10 +100,13 @@ class HipStages:
                                              work.data_ptr(), wb))
         return dict(colptr=colptr, pos=pos, s=s)
 
-    def colsum(self, ell_val, csc):
-        out = self.empty((csc["s"],))
-        _lib.check(self.L.flgp_dev_colsum(self._st(), ell_val.data_ptr(), csc["colptr"].data_ptr(), csc["pos"].data_ptr(),
-                                          csc["s"], out.data_ptr()))
+    def colsum(self, ell_idx, ell_val, s):
+        n, r = ell_idx.shape
+        out = self.empty((s,))
+        wb = self.L.flgp_dev_colsum_workspace(n, s)
+        work = self.empty((wb // 8 + 1,))
+        _lib.check(self.L.flgp_dev_colsum(self._st(), ell_idx.data_ptr(), ell_val.data_ptr(), n, r, s, out.data_ptr(),
+                                          work.data_ptr(), wb))
         return out
 
     def col_scale(self, ell_idx, ell_val, colsum, num_class, mode):
@@ -322,11 +325,11 @@ class HeatKernelPath:
         csc = S.csc(ell_idx, s)
         tm.mark("csc")
         if gl != 0:
-            c = self._all_reduce(S.colsum(ell_val, csc))                      # exchange 2a
+            c = self._all_reduce(S.colsum(ell_idx, ell_val, s))                # exchange 2a
             S.col_scale(ell_idx, ell_val, c, num_class if gl == 2 else None, 0)
         S.row_normalize(ell_val)
         # spectrum scaling (src/Spectrum.cpp:149-150)
-        c2 = self._all_reduce(S.colsum(ell_val, csc))                         # exchange 2b
+        c2 = self._all_reduce(S.colsum(ell_idx, ell_val, s))                   # exchange 2b
         S.col_scale(ell_idx, ell_val, c2, None, 1)
         tm.mark("laplacian")
         # k6: Gram, replicated top-K eigensolve

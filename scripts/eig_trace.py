@@ -22,8 +22,8 @@ num_class = P.cluster_sizes(X, anchors)
 knn_idx, _ = S.knn(X, anchors, r)
 ei, ev = S.lae(X, anchors, knn_idx)
 csc = S.csc(ei, s)
-c = S.colsum(ev, csc); S.col_scale(ei, ev, c, num_class, 0); S.row_normalize(ev)
-c2 = S.colsum(ev, csc); S.col_scale(ei, ev, c2, None, 1)
+c = S.colsum(ei, ev, s); S.col_scale(ei, ev, c, num_class, 0); S.row_normalize(ev)
+c2 = S.colsum(ei, ev, s); S.col_scale(ei, ev, c2, None, 1)
 G = S.gram(ei, ev, csc)
 torch.cuda.synchronize()
 ts = []

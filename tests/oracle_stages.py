@@ -39,8 +39,8 @@ class OracleStages:
     def csc(self, ell_idx, s):
         return dict(s=s, idx=ell_idx)
 
-    def colsum(self, ell_val, csc):
-        return torch.from_numpy(O.colsum(csc["idx"].numpy(), ell_val.numpy(), csc["s"]))
+    def colsum(self, ell_idx, ell_val, s):
+        return torch.from_numpy(O.colsum(ell_idx.numpy(), ell_val.numpy(), s))
 
     def col_scale(self, ell_idx, ell_val, colsum, num_class, mode):
         c = colsum.numpy()

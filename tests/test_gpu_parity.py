@@ -302,8 +302,10 @@ def test_cluster_normalized_needs_sizes():
 
 
 # ------------------------------------------------------------------------------ device stages
-def test_csc_colsum_gram_bit_exact(oracle, stages):
-    n, d, s, r = 3000, 3, 257, 7
+@pytest.mark.parametrize("n,d,s,r", [(3000, 3, 257, 7), (700, 2, 40, 3), (5000, 4, 65, 20), (2049, 3, 300, 1)])
+def test_csc_colsum_gram_bit_exact(oracle, stages, n, d, s, r):
+    """n > 1024 crosses the chunk boundary of the two-level column-sum order (oracle/flgp_oracle.c); few anchors and
+    r = 20 make lanes of one step collide on a column (the ballot-ranked passes of colsum_chunk_kernel)."""
     X, U0, U = make_case(n, d, s, r, seed=77)
     ei, zn = oracle.cross_similarity(X, U, r, gl="normalized")
     d_ei = torch.from_numpy(ei).cuda(); d_ev = torch.from_numpy(zn).cuda()
@@ -314,9 +316,9 @@ def test_csc_colsum_gram_bit_exact(oracle, stages):
     for j in (0, 1, s // 2, s - 1):
         seg = pos[colptr[j]:colptr[j + 1]]
         assert (np.diff(seg) > 0).all() and (ei.ravel()[seg] == j).all()   # stable: rows ascending
-    np.testing.assert_array_equal(stages.colsum(d_ev, csc).cpu().numpy(), oracle.colsum(ei, zn, s))
+    np.testing.assert_array_equal(stages.colsum(d_ei, d_ev, s).cpu().numpy(), oracle.colsum(ei, zn, s))
     av, _ = oracle.scale_A(ei, zn, s)
-    c = stages.colsum(d_ev, csc)
+    c = stages.colsum(d_ei, d_ev, s)
     stages.col_scale(d_ei, d_ev, c, None, 1)
     np.testing.assert_array_equal(d_ev.cpu().numpy(), av)
     G = stages.gram(d_ei, d_ev, csc).cpu().numpy()
