@@ -246,6 +246,7 @@ class PathResult:
     ell_idx: torch.Tensor = None
     ell_val: torch.Tensor = None
     knn_idx: torch.Tensor = None
+    G: torch.Tensor = None              # (s, s) Gram matrix the eigensolver saw (keep=True)
 
 
 class HeatKernelPath:
@@ -354,7 +355,7 @@ class HeatKernelPath:
         tm.mark("heat_kernel")
         res = PathResult(values=values, vectors=vectors, H=H, stage_ms=tm.result(), eig_info=info)
         if keep:
-            res.ell_idx, res.ell_val, res.knn_idx = ell_idx, ell_val, knn_idx
+            res.ell_idx, res.ell_val, res.knn_idx, res.G = ell_idx, ell_val, knn_idx, G
         return res
 
 

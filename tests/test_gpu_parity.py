@@ -776,8 +776,10 @@ def test_pipeline_matches_host_entry_points(oracle, stages):
 
 # ------------------------------------------------------------------------------ full size (BASELINE configs[2])
 def test_full_size_properties(oracle, stages):
-    """n = 1e6, d = 16, s = 5000, r = 10, K = 200, m = 1000 -- one pass, checked through
-    size-independent properties plus an oracle spot check of the bit-exact stages."""
+    """BASELINE configs[2] at full size, n = 1e6, d = 16, s = 5000, r = 10, K = 200, m = 1000, against the oracle run on
+    the same 1e6 rows: neighbour sets, LAE / Laplacian values and the Gram matrix bit-exact, eigenvalues 1e-10 against
+    LAPACK on the oracle's Gram matrix, covariance entries 1e-8 of max|H| against the oracle's chain -- plus the
+    size-independent properties."""
     n, d, s, r, K, m, t = 1_000_000, 16, 5000, 10, 200, 1000, 10.0
     X = synth.gaussian_mixture(n, d)
     sel = np.sort(synth.random_anchor_rows(n, s))
@@ -787,26 +789,101 @@ def test_full_size_properties(oracle, stages):
     sizes = path.cluster_sizes(dX, stages.anchor_prep(dU))
     assert float(sizes.sum()) == n
     res = path.run(dX, dU, PathConfig(s=s, r=r, K=K, t=t, m=m), n, 0, num_class=sizes, keep=True)
-    # k-NN + LAE: bit-exact against the oracle on a random sample of rows
+    # ---- the north_star sentence as a test: the ORACLE runs the similarity build on all n = 1e6 rows
+    U = np.asfortranarray(np.hstack([U0, sizes.cpu().numpy()[:, None]]))
+    ei_o, zn_o = oracle.cross_similarity(X, U, r, gl="cluster-normalized")            # k-NN + LAE + Laplacian
+    av_o, _ = oracle.scale_A(ei_o, zn_o, s)                                            # spectrum scaling
+    np.testing.assert_array_equal(res.ell_idx.cpu().numpy(), ei_o)                     # neighbour sets: every row
+    np.testing.assert_array_equal(res.ell_val.cpu().numpy(), av_o)                     # LAE / Laplacian / A values: bit-exact
     rows = np.random.default_rng(0).choice(n, 3000, replace=False)
     oi = oracle.knn(np.asfortranarray(X[rows]), U0, r)
-    np.testing.assert_array_equal(res.knn_idx[:, torch.from_numpy(rows).cuda()].cpu().numpy().T, oi)
+    np.testing.assert_array_equal(res.knn_idx[:, torch.from_numpy(rows).cuda()].cpu().numpy().T, oi)   # in distance order too
+    G_o = oracle.gram(ei_o, av_o, s)
+    np.testing.assert_array_equal(res.G.cpu().numpy(), G_o)                            # Gram: bit-exact
+    # eigenvalues against LAPACK on the oracle's Gram matrix; H against the oracle's own chain (eigh -> u = A v / sigma
+    # -> sqrt(n) -> heat kernel) on a slice of rows and the whole training block
+    import scipy.linalg as sl_
+    w_o, V_o = sl_.eigh(G_o, subset_by_index=[s - K, s - 1])
+    w_o = w_o[::-1]; V_o = V_o[:, ::-1]
+    vals = res.values.cpu().numpy()
+    np.testing.assert_allclose(vals ** 2, w_o, rtol=EIG_RTOL, atol=0)                  # root=True: values = sigma
+    pick = np.concatenate([np.arange(m), np.arange(123456, 123456 + 2048), np.arange(n - 1024, n)])
+    Uo = oracle.u_recover(ei_o[pick], av_o[pick], s, np.asfortranarray(V_o), np.sqrt(w_o))
+    vec_o = np.asfortranarray(Uo * (np.sqrt(float(n)) / np.sqrt(float(pick.size))))    # (the oracle scales by sqrt(rows given))
+    H_o = oracle.hk_from_spectrum(np.sqrt(w_o), vec_o, K, t, np.arange(pick.size), np.arange(m))
+    H_d = res.H[:, torch.from_numpy(pick).cuda()].cpu().numpy().T                      # (rows, m)
+    assert np.abs(H_d - H_o).max() <= H_RTOL * np.abs(H_o).max(), np.abs(H_d - H_o).max() / np.abs(H_o).max()
     assert int(res.ell_idx.min()) >= 0 and int(res.ell_idx.max()) < s
     assert bool((res.ell_idx[:, 1:] > res.ell_idx[:, :-1]).all())            # CSR inner order, no duplicates
     # spectrum: sigma_1 = 1, descending, V^T V = n I
-    vals = res.values.cpu().numpy()
     assert abs(vals[0] - 1.0) < 1e-6 and (np.diff(vals) <= 1e-12).all() and vals[-1] > 0
     VtV = (res.vectors @ res.vectors.T / n).cpu().numpy()
     np.testing.assert_allclose(VtV, np.eye(K), atol=1e-8)
-    # H on the training block: symmetric PSD; equals V diag(w) V^T recomputed in torch fp64 on a slice
+    # H on the training block: symmetric PSD
     Htrain = res.H[:, :m].cpu().numpy()                                       # (m, m)
     np.testing.assert_allclose(Htrain, Htrain.T, atol=1e-8 * np.abs(Htrain).max())
     assert np.linalg.eigvalsh(0.5 * (Htrain + Htrain.T)).min() > -1e-6 * np.abs(Htrain).max()
-    w = torch.exp(-t * (1.0 - res.values))
-    sl = slice(123456, 123456 + 4096)
-    ref = (res.vectors[:, :m].T * w) @ res.vectors[:, sl]                      # (m, 4096)
-    got = res.H[:, sl]
-    assert float((got - ref).abs().max()) <= 1e-10 * float(ref.abs().max())
+
+
+def test_c2_swiss_roll_regression_config(oracle):
+    """BASELINE configs[1]: Swiss roll n = 1e5, d = 3, s = 2000, r = 5, K = 100 -- the covariance the regression driver
+    consumes, through the host entry point (the R boundary), against the oracle's svds route: eigenvalues 1e-10, every
+    entry of H within 1e-8 of max|H|."""
+    n, s, r, K, m, t = 100_000, 2000, 5, 100, 500, 10.0
+    X, _ = synth.swiss_roll(n)
+    sel = np.sort(synth.random_anchor_rows(n, s))
+    U0 = synth.anchors_from_rows(X, sel)
+    sizes = np.bincount(oracle.knn(X, U0, 1)[:, 0], minlength=s).astype(float)
+    U = np.asfortranarray(np.hstack([U0, sizes[:, None]]))
+    models = dict(kernel="lae", gl="cluster-normalized", root=True)
+    ep = api.heat_kernel_spectrum_cpp(X[:m], X[m:], s, r, K, models, U=U)
+    vals_o, vec_o = oracle.heat_kernel_spectrum(X, U, r, K, gl="cluster-normalized", root=True, method="svds")
+    np.testing.assert_allclose(ep.values, vals_o, rtol=EIG_RTOL, atol=0)
+    H = api.heat_kernel_covariance_rcpp(X[:m], X[m:], s, r, t, K=K, U=U)
+    H_o = oracle.hk_from_spectrum(vals_o, vec_o, K, t, np.arange(n), np.arange(m))
+    assert H.shape == (n, m)
+    assert np.abs(H - H_o).max() <= H_RTOL * np.abs(H_o).max(), np.abs(H - H_o).max() / np.abs(H_o).max()
+    Z = api.cross_similarity_lae_cpp(X, U, r, "cluster-normalized")
+    ei_o, zn_o = oracle.cross_similarity(X, U, r, gl="cluster-normalized")
+    np.testing.assert_array_equal(Z.indices.reshape(n, r), ei_o)
+    np.testing.assert_array_equal(Z.data.reshape(n, r), zn_o)
+
+
+def test_c5_nystrom_full_size(oracle, stages):
+    """BASELINE configs[4]: n = 5e6, d = 64, s = 10000, K = 500, the Nystrom-extension spectrum, at full size on one GPU.
+    The extension is row-local given the anchors, so the numpy restatement on a sample of rows (with all 10^4 anchors:
+    the dense 10^4 x 10^4 eigenproblem in LAPACK) checks the full-size run; plus the properties the whole result must
+    have.  The cloud is drawn on the device (the host generator needs minutes for 3.2e8 normals)."""
+    n, d, s, K, a2 = 5_000_000, 64, 10_000, 500, 1.0
+    g = torch.Generator(device="cuda"); g.manual_seed(20241022)
+    centers = 2.0 * torch.randn((16, d), generator=g, device="cuda", dtype=torch.float64)
+    comp = torch.randint(0, 16, (n,), generator=g, device="cuda")
+    X = torch.empty((d, n), dtype=torch.float64, device="cuda")                 # column-major n x d
+    for k in range(d):                                                          # a column at a time: no n x d temporaries
+        X[k] = centers[comp, k] + torch.randn((n,), generator=g, device="cuda", dtype=torch.float64)
+    X /= float(np.sqrt(d))
+    sel = torch.randperm(n, generator=g, device="cuda")[:s].sort().values
+    U = X[:, sel].contiguous()                                                   # (d, s)
+    values, vectors = stages.nystrom(X, U, a2, K)
+    torch.cuda.synchronize()
+    assert values.shape == (K,) and vectors.shape == (K, n)
+    vals = values.cpu().numpy()
+    assert abs(vals[0] - 1.0) < 1e-4 and (np.diff(vals) <= 1e-12).all() and vals[-1] > 0   # (1e-9 guards on row sums of ~1e-4)
+    assert bool(torch.isfinite(vectors).all())
+    # the trivial pair: W 1 = 1, so the first extended vector is constant (+-1 after the reference's scaling)
+    v0 = vectors[0]
+    assert float((v0 - v0[0]).abs().max()) < 1e-4 * float(v0[0].abs())
+    # the oracle on a sample of rows + the anchors themselves (X = U rows reproduce the anchor eigenvectors)
+    rows = torch.from_numpy(np.random.default_rng(1).choice(n, 1500, replace=False)).cuda()
+    Xs = X[:, rows].T.cpu().numpy(); Uh = U.T.cpu().numpy()
+    vals_o, vec_o = oracle.np_nystrom_eigenpair(Xs, Uh, a2, K)
+    np.testing.assert_allclose(vals, vals_o, rtol=EIG_RTOL, atol=0)
+    got = vectors[:, rows].T.cpu().numpy()
+    sign = np.sign(np.sum(got * vec_o, axis=0))
+    err = np.max(np.abs(got * sign - vec_o), axis=0) / np.max(np.abs(vec_o), axis=0)
+    gap = np.minimum(np.abs(np.diff(vals_o, prepend=np.inf)), np.abs(np.diff(vals_o, append=-np.inf))) / vals_o[0]
+    assert np.max(err[:-1] * gap[:-1]) < 1e-9, float(np.max(err[:-1] * gap[:-1]))
+    assert err[0] < 1e-10
 
 
 # ------------------------------------------------------------------------------ row sharding on the real stages
