@@ -47,11 +47,12 @@ def parse():
     ap.add_argument("--K", type=int, default=200)
     ap.add_argument("--m", type=int, default=1000)
     ap.add_argument("--t", type=float, default=10.0)
-    ap.add_argument("--cpu-rows", type=int, default=20000, help="rows of the bounded CPU-baseline sample")
+    ap.add_argument("--cpu-rows", type=int, default=100000, help="rows of the bounded CPU-baseline sample (BASELINE.md: an n = 1e5 slice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--tune", action="append", default=[], help="key=value tuning knobs (experiments)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events (no roofline object)")
+    ap.add_argument("--no-e2e", action="store_true", help="skip the host-boundary (PCIe-inclusive) timing of the C entry point")
     return ap.parse_args()
 
 
@@ -94,7 +95,8 @@ def cpu_baseline(args, X_rows, U_np, sizes_np):
     return {
         "value": args.n / total, "unit": "points/s", "cores": int(O.threads()), "kind": "port",
         "sample": f"first {nc} of {args.n} rows for k-NN/LAE/Laplacian/heat-kernel (scaled x{scale:.0f}), "
-                  f"ARPACK svds at full s={args.s}, K={args.K} on that sample (counted once, unscaled)",
+                  f"ARPACK svds at full s={args.s}, K={args.K} on that sample (counted once, unscaled); "
+                  f"{int(O.threads())} OpenMP threads for the per-point stages, scipy's ARPACK + BLAS for svds",
         "stage_seconds_on_sample": {k: round(v, 4) for k, v in t.items()},
     }
 
@@ -123,6 +125,13 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        # first collective right away (before any kernel of the path): RCCL builds its rings here, and the count of
+        # ranks that answered goes into the JSON line
+        seen = torch.ones(1, dtype=torch.int64, device=device)
+        dist.all_reduce(seen)
+        ranks_seen = int(seen.item())
+    else:
+        ranks_seen = 1
     stages = HipStages(device)
     path = HeatKernelPath(stages)
     L = _lib.lib()
@@ -197,8 +206,9 @@ def main():
         res = step()
         barrier()
         L.flgp_prof_enable(0)
-        for name in ["gemm_f64_kernel", "gemm_large", "gemm_medium", "gemm_small", "knn_kernel", "lae_kernel", "gram_kernel",
-                     "u_recover_kernel", "csc_build", "colsum_kernel", "jacobi_eig", "jacobi_refine"]:
+        for name in ["gemm_f64_kernel", "gemm_large", "gemm_medium", "gemm_small", "bsg_gemm_kernel", "bsg_pre_kernel",
+                     "small_gemm_kernel", "knn_kernel", "lae_kernel", "gram_kernel", "u_recover_kernel", "csc_build",
+                     "colsum_kernel", "jacobi_eig", "jacobi_refine"]:
             c2, ms2, w2 = prof_query(L, name)
             if c2:
                 kernels[name] = {"launches": c2, "ms": ms2, "avg_launch_ms": ms2 / c2, "work": w2}
@@ -216,13 +226,36 @@ def main():
         "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": f"Gaussian-mixture n={n} d={d} s={s} r={args.r} K={args.K} m={args.m} t={args.t} "
                                f"kernel=lae gl=cluster-normalized root=TRUE (BASELINE configs[{2 if world == 1 else 3}])",
-                   "parallelism": f"row-sharded x{world}", "rows_per_gpu": n_loc,
+                   "parallelism": f"row-sharded x{world}", "rows_per_gpu": n_loc, "ranks_seen": ranks_seen,
                    "eig": res.eig_info},
         "stage_ms_per_step": {k: v / args.steps for k, v in stage_acc.items()},
         "kernels_diagnostic_step": kernels,
     }
     if roof:
         out["roofline"] = roof
+    if rank == 0 and world == 1 and not args.no_e2e:
+        # what R sees: the C entry point with host buffers in and out (X up, H = n x m down through the pipelined
+        # copy).  Reported beside ms_per_step, never inside `value`.
+        try:
+            del res
+            torch.cuda.empty_cache()
+            U_h = np.asfortranarray(np.column_stack([np.ascontiguousarray(U.t().cpu().numpy()), num_class.cpu().numpy()]))
+            X_h = np.asfortranarray(X_np)
+            best = None
+            for _ in range(3):
+                H_h = np.empty((n, args.m), order="F")
+                t0 = time.perf_counter()
+                _lib.check(L.flgp_heat_kernel_covariance(X_h.ctypes.data, n, args.m, d, U_h.ctypes.data, s, d + 1, args.r, args.t,
+                                                         args.K, b"lae", b"cluster-normalized", 1, 0.1, H_h.ctypes.data))
+                dt = (time.perf_counter() - t0) * 1e3
+                best = dt if best is None else min(best, dt)
+                del H_h
+            out["t_e2e_ms"] = best
+            out["t_e2e_note"] = ("flgp_heat_kernel_covariance, host pointers in / out (X %.0f MB up, H %.1f GB down, pageable), "
+                                 "best of 3 calls" % (X_h.nbytes / 1e6, n * args.m * 8 / 1e9))
+        except Exception as e:  # pragma: no cover
+            out["t_e2e_ms"] = None
+            out["t_e2e_note"] = "failed: %r" % (e,)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         nc = min(args.cpu_rows, n_loc)
         U_np = np.ascontiguousarray(U.t().cpu().numpy())

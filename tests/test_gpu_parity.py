@@ -774,6 +774,30 @@ def test_pipeline_matches_host_entry_points(oracle, stages):
     np.testing.assert_array_equal(to_np_cm(res.knn_idx), oracle.knn(X, U0, r))
 
 
+def test_pipelined_copy_of_H_is_the_same_matrix(oracle):
+    """The host boundary sends H in column blocks (GEMM, PCIe and the host copy overlapped: csrc/capi.hip,
+    hk_ranges_to_host).  Forced down to many small blocks -- with a ragged last one -- it must deliver, bit for bit, the
+    matrix of the single-copy path, through both entry points that use it."""
+    L = _lib.lib()
+    X, U0, U = make_case(20000, 3, 300, 5, seed=31)
+    m = 333
+    models = dict(kernel="lae", gl="cluster-normalized", root=True)
+    try:
+        L.flgp_set_tuning(b"hk_pipelined_d2h", 0)
+        H0 = api.heat_kernel_covariance_cpp(X[:m], X[m:], 300, 5, 3.0, 40, models, 1, 0.1, U=U)
+        ep = api.heat_kernel_spectrum_cpp(X[:m], X[m:], 300, 5, 40, models, U=U)
+        G0 = api.HK_from_spectrum_cpp(ep, 40, 3.0, np.arange(100, 20000), np.arange(5, 305))
+        L.flgp_set_tuning(b"hk_pipelined_d2h", 1)
+        L.flgp_set_tuning(b"hk_block_mb", 1)            # 1 MB blocks: 6 columns of 20000 rows -> 56 blocks
+        H1 = api.heat_kernel_covariance_cpp(X[:m], X[m:], 300, 5, 3.0, 40, models, 1, 0.1, U=U)
+        G1 = api.HK_from_spectrum_cpp(ep, 40, 3.0, np.arange(100, 20000), np.arange(5, 305))
+    finally:
+        L.flgp_set_tuning(b"hk_pipelined_d2h", 1)
+        L.flgp_set_tuning(b"hk_block_mb", 512)
+    np.testing.assert_array_equal(H1, H0)
+    np.testing.assert_array_equal(G1, G0)
+
+
 # ------------------------------------------------------------------------------ full size (BASELINE configs[2])
 def test_full_size_properties(oracle, stages):
     """BASELINE configs[2] at full size, n = 1e6, d = 16, s = 5000, r = 10, K = 200, m = 1000, against the oracle run on
