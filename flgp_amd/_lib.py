@@ -50,6 +50,8 @@ _SIGNATURES = {
     "flgp_eigenpair_vtv": (c_int, [P, c_int, P, c_int, P]),
     "flgp_eigenpair_vty": (c_int, [P, c_int, P, c_int, P, c_int, P]),
     "flgp_eigenpair_vc": (c_int, [P, c_int, P, c_int, P, c_int, P]),
+    "flgp_eigenpair_predict_regression": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, c_double, c_double, c_double, P]),
+    "flgp_eigenpair_posterior_variance": (c_int, [P, c_int, P, c_int, P, c_int, c_double, c_double, c_double, P]),
     "flgp_eigenpair_free": (None, [P]),
     "flgp_kmeans_lloyd": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, P, P, P]),
     "flgp_nystrom_eigenpair": (c_int, [P, c_int, c_int, P, c_int, c_double, c_int, P, P]),

@@ -224,6 +224,26 @@ class ResidentEigenPair:
         check(_lib.lib().flgp_eigenpair_vc(self._h, int(K), _ptr(idx), idx.size, _ptr(C), C.shape[1], _ptr(out)))
         return out
 
+    def predict_regression_cpp(self, Y, idx0, idx1, K, pars, sigma, noisepar="same"):
+        """predict_regression_cpp (src/Predict.cpp:40-75) on the resident pair: Y (m x q) goes up, Y_pred (m_new x q)
+        comes down; the Woodbury / Cholesky algebra runs on the device.  ``pars = (t, noise)``."""
+        if noisepar != "same":
+            raise FlgpError(-3, 'predict_regression_cpp: only noisepar="same" is built on the device')
+        idx0 = np.ascontiguousarray(idx0, dtype=np.int32); idx1 = np.ascontiguousarray(idx1, dtype=np.int32)
+        Y = np.asfortranarray(np.asarray(Y, dtype=np.float64).reshape(idx0.size, -1))
+        out = np.zeros((idx1.size, Y.shape[1]), order="F")
+        check(_lib.lib().flgp_eigenpair_predict_regression(self._h, int(K), _ptr(idx0), idx0.size, _ptr(idx1), idx1.size, _ptr(Y),
+                                                           Y.shape[1], float(pars[0]), float(pars[1]), float(sigma), _ptr(out)))
+        return out
+
+    def posterior_covariance_regression(self, idx0, idx1, K, pars, sigma):
+        """posterior_covariance_regression (src/Utils.cpp:214-250): posterior variance of the rows idx1; ``pars = (t, var)``."""
+        idx0 = np.ascontiguousarray(idx0, dtype=np.int32); idx1 = np.ascontiguousarray(idx1, dtype=np.int32)
+        out = np.zeros(idx1.size)
+        check(_lib.lib().flgp_eigenpair_posterior_variance(self._h, int(K), _ptr(idx0), idx0.size, _ptr(idx1), idx1.size,
+                                                           float(pars[0]), float(pars[1]), float(sigma), _ptr(out)))
+        return out
+
     def to_host(self):
         values = np.zeros(self.K); vectors = np.zeros((self.n, self.K), order="F")
         check(_lib.lib().flgp_eigenpair_to_host(self._h, _ptr(values), _ptr(vectors)))

@@ -797,6 +797,158 @@ extern "C" int flgp_eigenpair_vc(const flgp_eigenpair *ep, int K, const int *idx
   return FLGP_OK;
 }
 
+// ---- regression consumers of the resident pair: the Woodbury algebra stays on the device --------------
+namespace {
+struct GprCtx {
+  DevBuf ls, l, flag;
+  int prepare(hipStream_t st, const flgp_eigenpair *ep, int K, double t) {
+    FLGP_TRY(ls.alloc(sizeof(double) * (size_t)K)); FLGP_TRY(l.alloc(sizeof(double) * (size_t)K));
+    FLGP_TRY(flag.alloc(sizeof(int)));
+    FLGP_HIP(hipMemsetAsync(flag.p, 0, sizeof(int), st));
+    return gpr_weights(st, (const double *)ep->values.p, K, t, ls.as<double>(), l.as<double>());
+  }
+  int verdict(hipStream_t st, const char *who) {   // synchronises
+    int h = 0;
+    FLGP_HIP(hipMemcpyAsync(&h, flag.p, sizeof(int), hipMemcpyDeviceToHost, st));
+    FLGP_HIP(hipStreamSynchronize(st));
+    if (h) { set_error("%s: the system matrix is not positive definite (Cholesky pivot <= 0)", who); return FLGP_ERR_NOCONV; }
+    return FLGP_OK;
+  }
+};
+// device index array of a gather (nullptr for a contiguous range)
+int upload_idx(hipStream_t st, const int *idx, int cnt, DevBuf &buf, const int **d_out, int *row0) {
+  *d_out = nullptr; *row0 = 0;
+  if (is_range(idx, cnt)) { *row0 = cnt ? idx[0] : 0; return FLGP_OK; }
+  FLGP_TRY(buf.alloc(sizeof(int) * (size_t)cnt));
+  FLGP_TRY(h2d(buf.p, idx, sizeof(int) * (size_t)cnt, st));
+  *d_out = buf.as<int>();
+  return FLGP_OK;
+}
+}  // namespace
+
+extern "C" int flgp_eigenpair_predict_regression(const flgp_eigenpair *ep, int K, const int *idx0, int m, const int *idx1,
+                                                 int mnew, const double *Y, int q, double t, double noise, double sigma,
+                                                 double *Y_pred) {
+  FLGP_REQUIRE(ep && idx0 && idx1 && Y && Y_pred, "predict_regression: null pointer");
+  FLGP_REQUIRE(K >= 1 && K <= ep->K && m >= 1 && mnew >= 1 && q >= 1, "predict_regression: bad shape (K=%d m=%d m_new=%d q=%d)", K, m, mnew, q);
+  const double c = noise + sigma;
+  FLGP_REQUIRE(c > 0.0, "predict_regression: noise + sigma must be positive");
+  for (int a = 0; a < m; ++a) FLGP_REQUIRE(idx0[a] >= 0 && idx0[a] < ep->n, "predict_regression: idx0[%d]=%d out of range", a, idx0[a]);
+  for (int a = 0; a < mnew; ++a) FLGP_REQUIRE(idx1[a] >= 0 && idx1[a] < ep->n, "predict_regression: idx1[%d]=%d out of range", a, idx1[a]);
+  Stream st;
+  FLGP_TRY(st.create());
+  GprCtx G;
+  FLGP_TRY(G.prepare(st.s, ep, K, t));
+  const double *dval = (const double *)ep->values.p, *dvec = (const double *)ep->vectors.p;
+  DevBuf dY, out;
+  FLGP_TRY(dY.alloc(sizeof(double) * (size_t)m * q));
+  FLGP_TRY(out.alloc(sizeof(double) * (size_t)mnew * q));
+  FLGP_TRY(h2d(dY.p, Y, sizeof(double) * (size_t)m * q, st.s));
+  if (m <= K) {
+    // Cvv + (sigma + noise) I, Cholesky, alpha = C^-1 Y, Y_pred = Cnv alpha        (src/Predict.cpp:48-58)
+    DevBuf i0, i1, C, Cnv, work;
+    const int *d0, *d1; int r0, r1;
+    FLGP_TRY(upload_idx(st.s, idx0, m, i0, &d0, &r0));
+    FLGP_TRY(upload_idx(st.s, idx1, mnew, i1, &d1, &r1));
+    FLGP_TRY(C.alloc(sizeof(double) * (size_t)m * m));
+    FLGP_TRY(Cnv.alloc(sizeof(double) * (size_t)mnew * m));
+    FLGP_TRY(work.alloc(flgp_dev_hk_workspace(std::max(m, mnew), m, K, 1)));
+    FLGP_TRY(flgp_dev_hk(st.s, dval, K, t, dvec, ep->n, d0, r0, m, dvec, ep->n, d0, r0, m, C.as<double>(), m, work.as<double>()));
+    FLGP_TRY(gpr_add_diag(st.s, C.as<double>(), m, sigma));
+    FLGP_TRY(gpr_add_diag(st.s, C.as<double>(), m, noise));
+    FLGP_TRY(flgp_dev_hk(st.s, dval, K, t, dvec, ep->n, d1, r1, mnew, dvec, ep->n, d0, r0, m, Cnv.as<double>(), mnew, work.as<double>()));
+    FLGP_TRY(chol_solve(st.s, C.as<double>(), m, dY.as<double>(), q, G.flag.as<int>()));
+    FLGP_TRY(gemm_launch(st.s, mnew, q, m, 1.0, Cnv.as<double>(), 1, mnew, dY.as<double>(), 1, m, 0.0, nullptr, 0, 0,
+                         out.as<double>(), 1, mnew, nullptr, 0, 0.0, nullptr));
+  } else {
+    // Woodbury: Q = Ls V^T V Ls + (noise + sigma) I  (K x K)                       (src/Predict.cpp:59-74)
+    GatheredV g0, g1;
+    FLGP_TRY(gather_v(st.s, ep, K, idx0, m, g0));
+    FLGP_TRY(gather_v(st.s, ep, K, idx1, mnew, g1));
+    DevBuf VtV, VtY, Q, R, T1, work;
+    const size_t we = (size_t)128 * K * K + (size_t)64 * K * q + 1024;
+    FLGP_TRY(VtV.alloc(sizeof(double) * (size_t)K * K)); FLGP_TRY(Q.alloc(sizeof(double) * (size_t)K * K));
+    FLGP_TRY(VtY.alloc(sizeof(double) * (size_t)K * q)); FLGP_TRY(R.alloc(sizeof(double) * (size_t)K * q));
+    FLGP_TRY(T1.alloc(sizeof(double) * (size_t)K * q)); FLGP_TRY(work.alloc(sizeof(double) * we));
+    FLGP_TRY(gemm_launch(st.s, K, K, m, 1.0, g0.V, g0.ld, 1, g0.V, 1, g0.ld, 0.0, nullptr, 0, 0, VtV.as<double>(), 1, K,
+                         work.as<double>(), we, 0.0, nullptr));
+    FLGP_TRY(gemm_launch(st.s, K, q, m, 1.0, g0.V, g0.ld, 1, dY.as<double>(), 1, m, 0.0, nullptr, 0, 0, VtY.as<double>(), 1, K,
+                         work.as<double>(), we, 0.0, nullptr));
+    FLGP_TRY(gpr_q(st.s, VtV.as<double>(), G.ls.as<double>(), K, c, Q.as<double>()));
+    FLGP_TRY(gpr_scale(st.s, VtY.as<double>(), G.ls.as<double>(), nullptr, K, q, R.as<double>()));          // Ls V^T Y
+    FLGP_TRY(chol_solve(st.s, Q.as<double>(), K, R.as<double>(), q, G.flag.as<int>()));                       // Q^-1 (.)
+    FLGP_TRY(gpr_scale(st.s, R.as<double>(), G.ls.as<double>(), nullptr, K, q, R.as<double>()));            // Ls (.)
+    // V^T alpha = (V^T Y - V^T V Ls Q^-1 Ls V^T Y) / (noise + sigma)
+    FLGP_TRY(gemm_launch(st.s, K, q, K, 1.0, VtV.as<double>(), 1, K, R.as<double>(), 1, K, 0.0, nullptr, 0, 0, T1.as<double>(), 1, K,
+                         nullptr, 0, 0.0, nullptr));
+    FLGP_TRY(gpr_diff(st.s, VtY.as<double>(), T1.as<double>(), 1.0 / c, (long)K * q, T1.as<double>()));
+    FLGP_TRY(gpr_scale(st.s, T1.as<double>(), G.l.as<double>(), nullptr, K, q, T1.as<double>()));           // exp(-t lam) (.)
+    FLGP_TRY(gemm_launch(st.s, mnew, q, K, 1.0, g1.V, 1, g1.ld, T1.as<double>(), 1, K, 0.0, nullptr, 0, 0, out.as<double>(), 1,
+                         mnew, nullptr, 0, 0.0, nullptr));
+  }
+  FLGP_TRY(d2h(Y_pred, out.p, sizeof(double) * (size_t)mnew * q, st.s));
+  return G.verdict(st.s, "predict_regression");
+}
+
+extern "C" int flgp_eigenpair_posterior_variance(const flgp_eigenpair *ep, int K, const int *idx0, int m, const int *idx1,
+                                                 int mnew, double t, double var, double sigma, double *cov) {
+  FLGP_REQUIRE(ep && idx0 && idx1 && cov, "posterior_variance: null pointer");
+  FLGP_REQUIRE(K >= 1 && K <= ep->K && m >= 1 && mnew >= 1, "posterior_variance: bad shape (K=%d m=%d m_new=%d)", K, m, mnew);
+  const double c = var + sigma;
+  FLGP_REQUIRE(c > 0.0, "posterior_variance: var + sigma must be positive");
+  for (int a = 0; a < m; ++a) FLGP_REQUIRE(idx0[a] >= 0 && idx0[a] < ep->n, "posterior_variance: idx0[%d]=%d out of range", a, idx0[a]);
+  for (int a = 0; a < mnew; ++a) FLGP_REQUIRE(idx1[a] >= 0 && idx1[a] < ep->n, "posterior_variance: idx1[%d]=%d out of range", a, idx1[a]);
+  Stream st;
+  FLGP_TRY(st.create());
+  GprCtx G;
+  FLGP_TRY(G.prepare(st.s, ep, K, t));
+  const double *dval = (const double *)ep->values.p, *dvec = (const double *)ep->vectors.p;
+  GatheredV g1;
+  FLGP_TRY(gather_v(st.s, ep, K, idx1, mnew, g1));
+  DevBuf out;
+  FLGP_TRY(out.alloc(sizeof(double) * (size_t)mnew));
+  if (m <= K) {
+    // K11 = C11 + (var + sigma) I; alpha = C21 K11^-1; beta = rowsum(C21 .* alpha)          (src/Utils.cpp:227-237)
+    DevBuf i0, i1, C, C12, X, work;
+    const int *d0, *d1; int r0, r1;
+    FLGP_TRY(upload_idx(st.s, idx0, m, i0, &d0, &r0));
+    FLGP_TRY(upload_idx(st.s, idx1, mnew, i1, &d1, &r1));
+    FLGP_TRY(C.alloc(sizeof(double) * (size_t)m * m));
+    FLGP_TRY(C12.alloc(sizeof(double) * (size_t)m * mnew)); FLGP_TRY(X.alloc(sizeof(double) * (size_t)m * mnew));
+    FLGP_TRY(work.alloc(flgp_dev_hk_workspace(m, std::max(m, mnew), K, 1)));
+    FLGP_TRY(flgp_dev_hk(st.s, dval, K, t, dvec, ep->n, d0, r0, m, dvec, ep->n, d0, r0, m, C.as<double>(), m, work.as<double>()));
+    FLGP_TRY(gpr_add_diag(st.s, C.as<double>(), m, c));
+    FLGP_TRY(flgp_dev_hk(st.s, dval, K, t, dvec, ep->n, d0, r0, m, dvec, ep->n, d1, r1, mnew, C12.as<double>(), m, work.as<double>()));
+    FLGP_HIP(hipMemcpyAsync(X.p, C12.p, sizeof(double) * (size_t)m * mnew, hipMemcpyDeviceToDevice, st.s));
+    FLGP_TRY(chol_solve(st.s, C.as<double>(), m, X.as<double>(), mnew, G.flag.as<int>()));
+    FLGP_TRY(gpr_rowdot(st.s, C12.as<double>(), X.as<double>(), mnew, m, g1.V, g1.ld, K, G.l.as<double>(), c, out.as<double>()));
+  } else {
+    // alpha = 1/(var+sigma) L V1^T (V1 - V1 Ls Q^-1 Ls V1^T V1) L; beta_i = V2(i,:) alpha V2(i,:)^T  (src/Utils.cpp:238-246)
+    GatheredV g0;
+    FLGP_TRY(gather_v(st.s, ep, K, idx0, m, g0));
+    DevBuf VtV, Q, R, T1, W, work;
+    const size_t we = (size_t)128 * K * K + 1024;
+    FLGP_TRY(VtV.alloc(sizeof(double) * (size_t)K * K)); FLGP_TRY(Q.alloc(sizeof(double) * (size_t)K * K));
+    FLGP_TRY(R.alloc(sizeof(double) * (size_t)K * K)); FLGP_TRY(T1.alloc(sizeof(double) * (size_t)K * K));
+    FLGP_TRY(W.alloc(sizeof(double) * (size_t)mnew * K)); FLGP_TRY(work.alloc(sizeof(double) * we));
+    FLGP_TRY(gemm_launch(st.s, K, K, m, 1.0, g0.V, g0.ld, 1, g0.V, 1, g0.ld, 0.0, nullptr, 0, 0, VtV.as<double>(), 1, K,
+                         work.as<double>(), we, 0.0, nullptr));
+    FLGP_TRY(gpr_q(st.s, VtV.as<double>(), G.ls.as<double>(), K, c, Q.as<double>()));
+    FLGP_TRY(gpr_scale(st.s, VtV.as<double>(), G.ls.as<double>(), nullptr, K, K, R.as<double>()));          // Ls V1^T V1
+    FLGP_TRY(chol_solve(st.s, Q.as<double>(), K, R.as<double>(), K, G.flag.as<int>()));
+    FLGP_TRY(gpr_scale(st.s, R.as<double>(), G.ls.as<double>(), nullptr, K, K, R.as<double>()));            // Ls Q^-1 Ls VtV
+    FLGP_TRY(gemm_launch(st.s, K, K, K, 1.0, VtV.as<double>(), 1, K, R.as<double>(), 1, K, 0.0, nullptr, 0, 0, T1.as<double>(), 1, K,
+                         nullptr, 0, 0.0, nullptr));
+    FLGP_TRY(gpr_diff(st.s, VtV.as<double>(), T1.as<double>(), 1.0 / c, (long)K * K, T1.as<double>()));     // (VtV - ...)/(var+sigma)
+    FLGP_TRY(gpr_scale(st.s, T1.as<double>(), G.l.as<double>(), G.l.as<double>(), K, K, T1.as<double>()));   // L (.) L
+    FLGP_TRY(gemm_launch(st.s, mnew, K, K, 1.0, g1.V, 1, g1.ld, T1.as<double>(), 1, K, 0.0, nullptr, 0, 0, W.as<double>(), 1,
+                         mnew, nullptr, 0, 0.0, nullptr));                                                  // V2 alpha
+    FLGP_TRY(gpr_rowquad(st.s, g1.V, g1.ld, W.as<double>(), mnew, K, G.l.as<double>(), c, out.as<double>()));
+  }
+  FLGP_TRY(d2h(cov, out.p, sizeof(double) * (size_t)mnew, st.s));
+  return G.verdict(st.s, "posterior_variance");
+}
+
 extern "C" void flgp_eigenpair_free(flgp_eigenpair *ep) { delete ep; }
 
 extern "C" int flgp_heat_kernel_spectrum(const double *X_all, int n, int d, const double *U, int s, int ucols,

@@ -77,6 +77,18 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
 constexpr int GEMM_MAX_TICKETS = 1024;
 
 
+// dense algebra of the regression consumers of an EigenPair (gpr.hip)
+int chol_solve(hipStream_t st, double *dA, int N, double *dB, int nrhs, int *d_flag);
+int gpr_weights(hipStream_t st, const double *d_values, int K, double t, double *d_ls, double *d_l);
+int gpr_q(hipStream_t st, const double *dVtV, const double *d_ls, int K, double c, double *dQ);
+int gpr_scale(hipStream_t st, const double *dM, const double *d_a, const double *d_b, int rows, int cols, double *d_out);
+int gpr_diff(hipStream_t st, const double *dX, const double *dY, double alpha, long count, double *d_out);
+int gpr_add_diag(hipStream_t st, double *dA, int N, double c);
+int gpr_rowquad(hipStream_t st, const double *dV2, long ld2, const double *dW, int mnew, int K, const double *d_l, double c,
+                double *d_cov);
+int gpr_rowdot(hipStream_t st, const double *dC21, const double *dAl, int mnew, int m, const double *dV2, long ld2, int K,
+               const double *d_l, double c, double *d_cov);
+
 // host wait for a stream that polls an event instead of sleeping in hipStreamSynchronize (eig.hip)
 hipError_t stream_wait(hipStream_t st);
 

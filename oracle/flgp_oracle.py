@@ -428,6 +428,62 @@ def np_hk(values, vectors, K, t, idx0, idx1):
     return (vectors[idx0, :K] * w[None, :]) @ vectors[idx1, :K].T
 
 
+def np_predict_regression(values, vectors, Y, idx0, idx1, K, pars, sigma):
+    """predict_regression_cpp with noisepar = "same" (reference src/Predict.cpp:40-75), restated line by line in numpy:
+    ``pars = (t, noise)``; the m <= K branch is GPML Algorithm 2.1 on the m x m kernel matrix, the m > K branch the
+    Woodbury form on the K x K matrix Q.  Returns Y_pred (m_new x q)."""
+    import scipy.linalg as sl
+    values = np.asarray(values, dtype=np.float64); vectors = np.asarray(vectors, dtype=np.float64)
+    Y = np.asarray(Y, dtype=np.float64).reshape(len(idx0), -1)
+    t, noise = float(pars[0]), float(pars[1])
+    m = Y.shape[0]
+    if m <= K:
+        Cvv = np_hk(values, vectors, K, t, idx0, idx0)                              # :48
+        C_noisy = Cvv.copy()
+        C_noisy[np.diag_indices(m)] += sigma                                       # :50
+        C_noisy[np.diag_indices(m)] += noise                                       # :51
+        Cnv = np_hk(values, vectors, K, t, idx1, idx0)                              # :52
+        alpha = sl.cho_solve(sl.cho_factor(C_noisy, lower=True), Y)                 # :55-56
+        return Cnv @ alpha                                                         # :57
+    lam = 1.0 - values[:K]                                                         # :60
+    V = vectors[idx0, :K]                                                          # :64
+    ls = np.exp(-0.5 * t * lam) + 0.0                                              # :65
+    Q = (ls[:, None] * (V.T @ V)) * ls[None, :]                                    # :66
+    Q[np.diag_indices(K)] += noise + sigma                                         # :67
+    x = sl.cho_solve(sl.cho_factor(Q, lower=True), ls[:, None] * (V.T @ Y))        # :68-69
+    alpha = 1.0 / (noise + sigma) * (Y - (V * ls[None, :]) @ x)                    # :69
+    Vnv = vectors[idx1, :K]                                                        # :71
+    return Vnv @ ((np.exp(-t * lam) + 0.0)[:, None] * (V.T @ alpha))               # :72
+
+
+def np_posterior_covariance_regression(values, vectors, idx0, idx1, K, pars, sigma):
+    """posterior_covariance_regression (reference src/Utils.cpp:214-250) in numpy: ``pars = (t, var)``; returns the
+    posterior variance of the rows idx1 (m_new,)."""
+    import scipy.linalg as sl
+    values = np.asarray(values, dtype=np.float64); vectors = np.asarray(vectors, dtype=np.float64)
+    m = len(idx0)
+    t, var = float(pars[0]), float(pars[1])
+    lam = 1.0 - values[:K]                                                         # :220
+    V2 = vectors[idx1, :K]                                                         # :223
+    L = np.exp(-t * lam)                                                           # :224
+    if m <= K:
+        C11 = np_hk(values, vectors, K, t, idx0, idx0)                              # :228
+        K11 = C11.copy(); K11[np.diag_indices(m)] += var + sigma                   # :229-230
+        C21 = np_hk(values, vectors, K, t, idx1, idx0)                              # :231
+        alpha = C21 @ sl.cho_solve(sl.cho_factor(K11, lower=True), np.eye(m))       # :233-234
+        beta = (C21 * alpha).sum(1)                                                # :235
+    else:
+        V1 = vectors[idx0, :K]                                                     # :237
+        ls = np.exp(-0.5 * t * lam) + 0.0                                          # :238
+        VtV = V1.T @ V1
+        Q = (ls[:, None] * VtV) * ls[None, :]                                      # :239
+        Q[np.diag_indices(K)] += var + sigma                                       # :240
+        inner = V1 - (V1 * ls[None, :]) @ sl.cho_solve(sl.cho_factor(Q, lower=True), ls[:, None] * VtV)   # :242
+        alpha = 1.0 / (var + sigma) * ((L[:, None] * (V1.T @ inner)) * L[None, :])  # :242
+        beta = (V2 * (V2 @ alpha)).sum(1)                                          # :243
+    return ((V2 * L[None, :]) * V2).sum(1) + var + sigma - beta                    # :246
+
+
 def np_nystrom_eigenpair(X_all, U, a2, K):
     """The Nystrom-extension spectrum the ``fit_nystrom_*`` drivers build per bandwidth ``a2`` (reference
     src/Fit.cpp:244-286; identical in :399-441, :918-960, :1063-1105 ...), restated line by line in numpy.

@@ -597,6 +597,38 @@ def test_resident_eigenpair_matches_host_path(oracle):
     rp.free(); up.free()
 
 
+
+@pytest.mark.parametrize("m,K,q", [(60, 40, 1), (40, 40, 2), (300, 40, 1), (900, 100, 3)])
+def test_resident_regression_prediction_and_posterior_variance(oracle, m, K, q):
+    """SURVEY 8f-2, finished in round 2: predict_regression_cpp (src/Predict.cpp:40-75) and
+    posterior_covariance_regression (src/Utils.cpp:214-250) on the resident pair -- both branches (m <= K: Cholesky of
+    the m x m kernel matrix; m > K: Woodbury on K x K) against the numpy restatements, index gathers and ranges."""
+    n = 3000
+    X, U0, U = make_case(n, 3, 200, 5, seed=77)
+    models = dict(kernel="lae", gl="cluster-normalized", root=True)
+    rp = api.heat_kernel_spectrum_resident(X[:m], X[m:], 200, 5, max(K, 100), models, U=U)
+    ep = rp.to_host()
+    rng = np.random.default_rng(m + K)
+    Y = rng.normal(size=(m, q))
+    sigma = 1e-3
+    for idx0, idx1 in [(np.arange(m), np.arange(m, n)), (rng.permutation(n)[:m], rng.permutation(n)[:777])]:
+        for t, noise in [(10.0, 0.1), (2.0, 1e-2)]:
+            ref = oracle.np_predict_regression(ep.values, ep.vectors, Y, idx0, idx1, K, (t, noise), sigma)
+            got = rp.predict_regression_cpp(Y, idx0, idx1, K, (t, noise), sigma)
+            np.testing.assert_allclose(got, ref, rtol=0, atol=1e-9 * np.abs(ref).max())
+            refv = oracle.np_posterior_covariance_regression(ep.values, ep.vectors, idx0, idx1, K, (t, noise), sigma)
+            gotv = rp.posterior_covariance_regression(idx0, idx1, K, (t, noise), sigma)
+            # the reference's formula is a difference of terms of size prior * |V^T V| / (var + sigma) (|V^T V| ~ m): two
+            # correct fp64 evaluations differ by that times a few eps, whatever the result's own size
+            prior = ((ep.vectors[idx1, :K] ** 2) * np.exp(-t * (1.0 - ep.values[:K]))).sum(1).max()
+            np.testing.assert_allclose(gotv, refv, rtol=0, atol=1e-9 * np.abs(refv).max() + 2e-15 * prior * m / (noise + sigma))
+            assert (gotv > 0).all()
+    with pytest.raises(api.FlgpError):
+        rp.predict_regression_cpp(Y, np.arange(m), np.array([n]), K, (1.0, 0.1), sigma)          # row out of range
+    with pytest.raises(api.FlgpError):
+        rp.posterior_covariance_regression(np.arange(m), np.arange(5), K, (1.0, 0.0), 0.0)       # var + sigma = 0
+    rp.free()
+
 @pytest.mark.parametrize("n,d,s,a2,K,seed", [(3000, 3, 300, 1.0, 30, 0), (5000, 7, 500, 0.5, 60, 1),
                                               (2000, 16, 257, 10.0, 20, 2), (700, 2, 64, 0.1, 64 // 4, 3)])
 def test_nystrom_eigenpair(oracle, n, d, s, a2, K, seed):
