@@ -393,6 +393,63 @@ __global__ __launch_bounds__(256) void u_recover_tiled_kernel(const int *__restr
       if (k0 + kq < K) out[(size_t)(k0 + kq) * ldo + i0 + i] = tile[kq][i];
 }
 
+// The same with KPL eigen-columns per lane (64 KPL per workgroup; K a multiple of KPL): a row of Vt is K * 8 contiguous
+// bytes, so one 8 KPL-byte load per lane takes 512 KPL bytes of it -- 1 / KPL as many gather instructions as the
+// 64-column kernel, and K = 200 is two column tiles at KPL = 2 (128 + 72) or one at KPL = 4 instead of four
+// (64 + 64 + 64 + 8, the last one all overhead).  ROWS rows per workgroup (a quarter per wave).
+template <int KPL, int ROWS>
+__global__ __launch_bounds__(256) void u_recover_wide_kernel(const int *__restrict__ ell_idx,
+                                                             const double *__restrict__ val, int n, int r,
+                                                             const double *__restrict__ Vt,
+                                                             const double *__restrict__ eig, int K, double scale,
+                                                             double *__restrict__ out, int ldo) {
+  typedef double vec_t __attribute__((ext_vector_type(KPL)));
+  constexpr int KT = 64 * KPL, RPW = ROWS / 4;
+  constexpr int UR = (RPW < U_RECOVER_UNROLL) ? RPW : U_RECOVER_UNROLL;
+  __shared__ double tile[KT][ROWS + 1];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long i0 = (long)blockIdx.x * ROWS;
+  const int k0 = blockIdx.y * KT;
+  const int k = k0 + KPL * lane;
+  const bool kok = k < K;                  // K % KPL == 0: a lane's columns are in or out together
+  double sg[KPL];
+#pragma unroll
+  for (int c = 0; c < KPL; ++c) { const double e = kok ? eig[k + c] : 1.0; sg[c] = __builtin_sqrt(e > 0.0 ? e : 0.0); }
+  const double inv_guard = kok ? 1.0 : 0.0;
+  const int kk = kok ? k : 0;
+  for (int il = wave * RPW; il < wave * RPW + RPW; il += UR) {
+    vec_t acc[UR];
+#pragma unroll
+    for (int u = 0; u < UR; ++u)
+#pragma unroll
+      for (int c = 0; c < KPL; ++c) acc[u][c] = 0.0;
+    for (int a = 0; a < r; ++a) {
+      vec_t v[UR];
+      double z[UR];
+#pragma unroll
+      for (int u = 0; u < UR; ++u) {
+        const long i = (i0 + il + u < n) ? i0 + il + u : n - 1;   // wave-uniform: scalar loads
+        z[u] = val[(size_t)i * r + a];
+        v[u] = *(const vec_t *)(Vt + (size_t)ell_idx[(size_t)i * r + a] * K + kk);
+      }
+#pragma unroll
+      for (int u = 0; u < UR; ++u)
+#pragma unroll
+        for (int c = 0; c < KPL; ++c) acc[u][c] += z[u] * v[u][c];
+    }
+#pragma unroll
+    for (int u = 0; u < UR; ++u)
+#pragma unroll
+      for (int c = 0; c < KPL; ++c)
+        tile[KPL * lane + c][il + u] = sg[c] > 0.0 ? ((acc[u][c] * inv_guard) / sg[c]) * scale : 0.0;
+  }
+  __syncthreads();
+  for (int e = tid; e < KT * ROWS; e += 256) {
+    const int kq = e / ROWS, i = e % ROWS;
+    if (k0 + kq < K && i0 + i < n) out[(size_t)(k0 + kq) * ldo + i0 + i] = tile[kq][i];
+  }
+}
+
 __global__ void values_out_kernel(const double *__restrict__ eig, int K, int root, double *__restrict__ values) {
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= K) return;
@@ -576,8 +633,17 @@ extern "C" int flgp_dev_u_recover(void *stream, const int *d_ell_idx, const doub
     if (d_work) {
       hipLaunchKernelGGL(transpose_v_kernel, dim3(ceil_div(s, 32), ceil_div(K, 32)), dim3(256), 0, st, dV, ldv, s, K,
                          d_work);
-      hipLaunchKernelGGL(u_recover_tiled_kernel, dim3(ceil_div(n, 64), ceil_div(K, 64)), dim3(256), 0, st, d_ell_idx,
-                         d_ell_val, n, r, d_work, d_eig, K, scale, d_vectors, ldo);
+      const int wide = tuning("u_recover_wide", 4);
+      if (wide >= 4 && K % 4 == 0) {
+        hipLaunchKernelGGL((u_recover_wide_kernel<4, 32>), dim3(ceil_div(n, 32), ceil_div(K, 256)), dim3(256), 0, st, d_ell_idx,
+                           d_ell_val, n, r, d_work, d_eig, K, scale, d_vectors, ldo);
+      } else if (wide >= 2 && K % 2 == 0) {
+        hipLaunchKernelGGL((u_recover_wide_kernel<2, 64>), dim3(ceil_div(n, 64), ceil_div(K, 128)), dim3(256), 0, st, d_ell_idx,
+                           d_ell_val, n, r, d_work, d_eig, K, scale, d_vectors, ldo);
+      } else {
+        hipLaunchKernelGGL(u_recover_tiled_kernel, dim3(ceil_div(n, 64), ceil_div(K, 64)), dim3(256), 0, st, d_ell_idx,
+                           d_ell_val, n, r, d_work, d_eig, K, scale, d_vectors, ldo);
+      }
     } else {
       hipLaunchKernelGGL(u_recover_kernel, dim3(ceil_div(n, 256), ceil_div(K, 8)), dim3(256), 0, st, d_ell_idx,
                          d_ell_val, n, r, dV, ldv, d_eig, K, scale, d_vectors, ldo);
