@@ -1454,7 +1454,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     // more to the stale interval than they gain), while the refinement runs on the second stream; the
     // rotation W is applied to the filtered block afterwards.  Not on the step that is expected to
     // converge: there the filter's products would be thrown away.
-    const bool overlap = can_overlap && do_rr && it >= 3 && !near_done &&
+    const bool overlap = can_overlap && do_rr && it >= tuning("eig_overlap_from_it", 3) && !near_done &&
                          rmax_prev <= 1e-6 * (double)tuning("eig_overlap_below_e6", 10000);
     double rmax = rmax_prev * rate, top = std::max(theta[0], 1e-300);
     if (do_rr && overlap) {
