@@ -3,7 +3,7 @@ counts products / Rayleigh-Ritz steps for algorithm variants before they are wri
 usage: python3 scripts/model_chfsi.py G.npy [variant options k=v ...]"""
 import sys, time, numpy as np
 G = np.load(sys.argv[1]); s = G.shape[0]
-opt = dict(K=200, guard_pct=25, amp=8, amp_early=3, cut_pct=90, lock=0, skip_rr0=0, skip_n=1, m0=5, m1=5, tol=5e-11, rr_every=3, amp_active=0, maxit=40, lock_q=16, guard_min=24, verbose=1)
+opt = dict(K=200, guard_pct=25, amp=8, amp_early=3, cut_pct=90, lock=0, skip_rr0=0, skip_n=1, m0=5, m1=5, lo=0.0, tol=5e-11, rr_every=3, amp_active=0, maxit=40, lock_q=16, guard_min=24, verbose=1)
 for kv in sys.argv[2:]:
     k, v = kv.split("="); opt[k] = float(v) if "." in v or "e" in v else int(v)
 K = opt["K"]; tol = opt["tol"]
@@ -64,7 +64,8 @@ for it in range(opt["maxit"]):
         cut_pos = Kact + (ba - Kact) * opt["cut_pct"] // 100
         cut = theta[min(ba - 1, max(Kact, cut_pos - 1))]
         cut = min(cut, 0.999 * top)
-        c = e = 0.5 * cut; g1 = (top - c) / e
+        lo_ = opt['lo'] if it >= 1 else 0.0
+        c = 0.5 * (cut + lo_); e = 0.5 * (cut - lo_); g1 = (top - c) / e
         ampexp = opt["amp_early"] if it < 2 else opt["amp"]
         m = int(np.floor(np.arccosh(10.0 ** ampexp) / np.arccosh(max(g1, 1 + 1e-12)))); m = max(2, min(m, opt.get("mmax", 40)))
         sigma1 = e / (top - c)
