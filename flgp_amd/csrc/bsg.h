@@ -43,6 +43,11 @@ struct BsG {
   double h_bounds[2] = {0.0, 0.0};   // 1-norm of G (>= lambda_max), trace of G; valid like h_meta
   int *meta = nullptr;            // device: see BSG_M_* in bsg.hip
   int *head = nullptr;            // work-queue heads of the product kernel (ring of 2)
+  double *lz = nullptr;           // Lanczos vectors / partial sums / (alpha, beta)
+  double h_ab[64] = {0};          // (alpha_k, beta_k) of the Lanczos steps, valid after lz_ev
+  bool lanczos = false;
+  hipEvent_t lz_ev = nullptr;
+  double lambda_lo = 0.0;         // safe-side estimate of lambda_min(G) (0 when there is none): set by bsg_finish
   double *T[3] = {nullptr, nullptr, nullptr};   // b x s blocks of the transposed filter
   int h_meta[BSG_META] = {0};     // host copy, valid after the stream has been synchronised
   int launches = 0;               // products issued
@@ -55,7 +60,7 @@ void bsg_carve(BsG &g, char *&p, int s, int b);
 // Enqueues the whole set-up (one host round trip in the middle, for the 64-cluster chain).  On return the device work
 // is queued and the bookkeeping is on its way to g.h_meta: call bsg_finish() after the next stream synchronisation and
 // before the first product.
-int bsg_setup(hipStream_t st, const double *dG, int ldg, int s, BsG &g);
+int bsg_setup(hipStream_t st, const double *dG, int ldg, int s, BsG &g, hipStream_t side = nullptr, hipEvent_t side_ev = nullptr);
 // after a synchronisation: decides g.on (false when G does not concentrate: the caller multiplies with the dense G)
 void bsg_finish(BsG &g);
 // out_t = alpha X_t (P G P^T) + beta E_t + gamma E2_t   (all b x s, b contiguous; E_t / E2_t may be null; out_t must not
