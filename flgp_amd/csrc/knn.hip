@@ -22,23 +22,66 @@
 
 namespace flgp {
 
+// rows of the fp64 panel: s rounded up to the kernels' anchor tile
+__host__ __device__ inline int anchor_pad_rows(int s) { return (s + 127) / 128 * 128; }
+
+// ---- the screening copy of the anchors (knn_screen_kernel) ----
+// Behind the fp64 panel (rows_pad x dpad doubles at Ut, |u|^2 at uu) sits a copy for the matrix-core screen: every
+// coordinate split into two bf16 pieces, u = hi + lo + eps with |eps| <= 2^-17 |u|, laid out as v_mfma_f32_32x32x16_bf16
+// A operands -- per tile of 32 anchors 2 KB: hi[khalf 2][anchor 32][8], then lo the same -- and two tables of
+// accumulator start values, C1_j = -(|u_j|^2 / 2)(1 + mu) and C2_j = -(|u_j|^2 / 2)(1 - mu) (rows_pad floats each, at
+// uu + rows_pad).  Anchors the screen has no say about (|u|^2 above 1e30 or not finite) get a zero row, C1 = -3e38 (never
+// a bound) and C2 = +3e38 (always a candidate); padding rows C1 = C2 = -3e38.  Written for dpad = 8 and 16 only;
+// flgp_dev_anchor_rows() hands out room for it.
+constexpr float KNN_SCREEN_MU = 1.220703125e-4f;   // 2^-13, see knn_screen_kernel
+constexpr float KNN_SCREEN_BIG = 3.0e38f;
+__device__ __host__ inline const unsigned short *screen_panel(const double *Ut, int s, int dpad) {
+  return (const unsigned short *)(Ut + (size_t)anchor_pad_rows(s) * dpad);
+}
+__device__ __host__ inline const float *screen_cinit(const double *uu, int s) { return (const float *)(uu + anchor_pad_rows(s)); }
+
+__device__ __forceinline__ unsigned short bf16_rne(float f) {   // finite f well inside the range
+  unsigned u = __float_as_uint(f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float bf16_as_f32(unsigned short h) { return __uint_as_float((unsigned)h << 16); }
+__device__ __forceinline__ void bf16_split(double x, unsigned short &hi, unsigned short &lo) {
+  hi = bf16_rne((float)x);
+  lo = bf16_rne((float)(x - (double)bf16_as_f32(hi)));
+}
+
 __global__ void anchor_prep_kernel(const double *__restrict__ U, int s, int s_pad, int ldu, int d, int dpad,
                                    double *__restrict__ Ut, double *__restrict__ uu) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= s_pad) return;
+  const bool screen = dpad == 8 || dpad == 16;
+  unsigned short *tile = (unsigned short *)(Ut + (size_t)s_pad * dpad) + (size_t)(j >> 5) * 1024 + (j & 31) * 8;
+  float *c1 = (float *)(uu + s_pad), *c2 = c1 + s_pad;
+  double acc = 0.0;
   if (j >= s) {  // padding rows: never selected (|u|^2 = +inf makes D = +inf, and inf < thr is false)
     for (int k = 0; k < dpad; ++k) Ut[(size_t)j * dpad + k] = 0.0;
     uu[j] = __builtin_inf();
-    return;
+  } else {
+    for (int k = 0; k < d; ++k) {
+      const double u = U[(size_t)k * ldu + j];
+      Ut[(size_t)j * dpad + k] = u;
+      acc = (k == 0) ? u * u : __builtin_fma(u, u, acc);
+    }
+    for (int k = d; k < dpad; ++k) Ut[(size_t)j * dpad + k] = 0.0;
+    uu[j] = acc;
   }
-  double acc = 0.0;
-  for (int k = 0; k < d; ++k) {
-    const double u = U[(size_t)k * ldu + j];
-    Ut[(size_t)j * dpad + k] = u;
-    acc = (k == 0) ? u * u : __builtin_fma(u, u, acc);
+  if (!screen) return;
+  const bool usable = j < s && acc <= 1e30;       // false for NaN
+  for (int k = 0; k < 16; ++k) {
+    unsigned short hi = 0, lo = 0;
+    if (usable && k < d) bf16_split(U[(size_t)k * ldu + j], hi, lo);
+    const int at = (k >> 3) * 256 + (k & 7);
+    tile[at] = hi;
+    tile[512 + at] = lo;
   }
-  for (int k = d; k < dpad; ++k) Ut[(size_t)j * dpad + k] = 0.0;
-  uu[j] = acc;
+  c1[j] = usable ? (float)(-0.5 * acc * (1.0 + (double)KNN_SCREEN_MU)) : -KNN_SCREEN_BIG;
+  c2[j] = usable ? (float)(-0.5 * acc * (1.0 - (double)KNN_SCREEN_MU)) : (j < s ? KNN_SCREEN_BIG : -KNN_SCREEN_BIG);
 }
 
 // Sorted list of the RCAP smallest (value, index) pairs, ascending.  The first RCAP - r slots
@@ -66,6 +109,21 @@ struct TopList {
       bi[k] = c1 ? bi[k - 1] : (c0 ? j : bi[k]);
     }
     const bool c0 = D < bd[0];
+    bd[0] = c0 ? D : bd[0];
+    bi[0] = c0 ? j : bi[0];
+  }
+  // order by (distance, index): the list a scan in ascending index with the strict '<' above ends with, whatever the
+  // order the candidates come in.  D must be below +inf (the scan never takes such an anchor).
+  __device__ __forceinline__ bool before(double D, int j, int k) const { return D < bd[k] || (D == bd[k] && j < bi[k]); }
+  __device__ __forceinline__ void insert_lex(double D, int j) {
+#pragma unroll
+    for (int k = RCAP - 1; k >= 1; --k) {
+      const bool c1 = before(D, j, k - 1);
+      const bool c0 = before(D, j, k);
+      bd[k] = c1 ? bd[k - 1] : (c0 ? D : bd[k]);
+      bi[k] = c1 ? bi[k - 1] : (c0 ? j : bi[k]);
+    }
+    const bool c0 = before(D, j, 0);
     bd[0] = c0 ? D : bd[0];
     bi[0] = c0 ? j : bi[0];
   }
@@ -205,6 +263,287 @@ __global__ __launch_bounds__(256) void knn_kernel(const double *__restrict__ X, 
           idx_out[(size_t)slot * ldo + i] = ((unsigned)bj_ < (unsigned)s) ? bj_ : slot;
           if (dist_out) dist_out[(size_t)slot * ldo + i] = top[p].bd[k];
         }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k-NN with a matrix-core screen (round 2; d <= 16, r <= 16, 512 <= s < 65536).
+//
+// The r nearest anchors and their distances stay EXACT -- the oracle's fp64 chain, bit for bit -- but that chain is only
+// run for the dozen anchors per point that can matter.  The rest is decided by E^_j, a bf16x3 matrix-core evaluation of
+//     E_j = x . u_j - |u_j|^2 / 2          (D_j = |x|^2 - 2 E_j: larger E = nearer),
+// x = hi + lo + eps in bf16 pieces and likewise u; one v_mfma_f32_32x32x16_bf16 each for hi.hi, hi.lo and lo.hi on top of
+// an accumulator that starts at -|u_j|^2 / 2: 32 anchors x 32 points and all 16 coordinates per instruction.
+//   Error: dropping eps and lo.lo costs <= 3 * 2^-17 sum|x_k u_k|; 49 fp32 accumulations of exact bf16 products cost
+//   <= 50 * 2^-22 (sum|x_k u_k| + |u|^2 / 2) even if the hardware truncates; sum|x_k u_k| <= (|x|^2 + |u|^2) / 2; the oracle's
+//   own fp64 rounding is 2^-29 of that.  Together |E^ - E| < 2^-15 (|x|^2 + |u|^2) / 2.  The screen budgets four times
+//   that: eta_j = mu (|x|^2 + |u_j|^2) / 2, mu = 2^-13, its |u_j|^2 half folded into the start values (C1, C2 of the panel),
+//   its |x|^2 half into the point's threshold.
+//   Pass 1 (start C1): every lane keeps the maximum of each of its 16 accumulator slots over all tiles: 32 groups of
+//   anchors per point (two lanes share a point), each maximum a LOWER bound on some E_j once mu |x|^2 / 2 is taken off.
+//   The r-th largest of the 32 is a bound r distinct anchors beat: tau.
+//   Pass 2 (start C2): anchor j can only be among the r nearest if E^_j + eta_j >= tau; everything else has r anchors
+//   STRICTLY nearer and is dropped.  At s = 5000, r = 10 about 13 anchors per point are left.
+//   Then one lane per point runs the exact chain on its candidates (anchor row gathered from the fp64 panel) into a
+//   list ordered by (distance, index) -- what the oracle's ascending scan with strict '<' ends with.
+// Where the screen has no say the exact arithmetic decides alone: points with |x|^2 outside [1e-30, 1e30] or not finite,
+// and points whose candidate queue overflows (more than 32 per half: duplicates of one anchor, say), are scanned against
+// all anchors by their whole wave, exactly; anchors with |u|^2 above 1e30 are candidates for every point.
+// ------------------------------------------------------------------------------------------
+typedef __bf16 kbf8 __attribute__((ext_vector_type(8)));
+typedef float kf16 __attribute__((ext_vector_type(16)));
+typedef float kf4 __attribute__((ext_vector_type(4)));
+constexpr int KNN_SCREEN_QC = 32;         // candidates per (point, half)
+
+template <int N>
+__device__ __forceinline__ void sort_desc(float (&v)[N]) {   // bitonic network, all indices static
+#pragma unroll
+  for (int k = 2; k <= N; k *= 2) {
+#pragma unroll
+    for (int j = k / 2; j > 0; j /= 2) {
+#pragma unroll
+      for (int i = 0; i < N; ++i) {
+        const int l = i ^ j;
+        if (l > i) {
+          const float a = v[i], b = v[l];
+          const bool desc = (i & k) == 0;
+          v[i] = desc ? fmaxf(a, b) : fminf(a, b);
+          v[l] = desc ? fminf(a, b) : fmaxf(a, b);
+        }
+      }
+    }
+  }
+}
+
+template <int DP, int RCAP>
+__global__ __launch_bounds__(256, 2) void knn_screen_kernel(const double *__restrict__ X, int n, int ldx, int d,
+                                                         const double *__restrict__ Ut, const double *__restrict__ uu,
+                                                         int s, int r, int *__restrict__ idx_out,
+                                                         double *__restrict__ dist_out, int ldo) {
+  constexpr int NT = 256, PB = 256, CH = 128, QC = KNN_SCREEN_QC;
+  static_assert(DP == 8 || DP == 16, "the screen panel is written for dpad 8 and 16");
+  __shared__ uint4 abuf[2][CH * 4];                 // 128 anchors x 64 B
+  __shared__ __attribute__((aligned(16))) float cbuf[2][CH];
+  __shared__ __attribute__((aligned(16))) unsigned short q[QC * 2 * PB];   // [entry][half][point]; first the sorted maxima
+  __shared__ int qcnt[2 * PB];
+  float *sg = (float *)q;                           // [lane of the workgroup][17]
+  static_assert(sizeof(q) >= sizeof(float) * NT * 17, "scratch for the sorted maxima");
+
+  const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, kh = l >> 5, col = l & 31;
+  const long base = (long)blockIdx.x * PB;
+  const int s_pad = anchor_pad_rows(s);
+  const int nch = s_pad / CH;
+  const uint4 *__restrict__ panel = (const uint4 *)screen_panel(Ut, s, DP);
+  const float *__restrict__ ctab = screen_cinit(uu, s);
+
+  // ---- the points as B operands: lane = (point col of tile t, coordinates 8 kh .. 8 kh + 7)
+  kbf8 bhi[2], blo[2];
+  float xxf[2];
+  bool off[2];                                      // the screen has no say about this point
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    long i = base + w * 64 + t * 32 + col;
+    if (i >= n) i = n - 1;
+    double part = 0.0;
+    unsigned short h[8], lo[8];
+    double xv[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      const int k = 8 * kh + kk;
+      xv[kk] = (k < d) ? X[(size_t)k * ldx + i] : 0.0;
+      part = __builtin_fma(xv[kk], xv[kk], part);
+    }
+    const double xx = part + __shfl_xor(part, 32);
+    off[t] = !(xx >= 1e-30 && xx <= 1e30);
+    xxf[t] = (float)xx;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+      h[kk] = 0; lo[kk] = 0;
+      if (!off[t]) bf16_split(xv[kk], h[kk], lo[kk]);
+    }
+    uint4 ph, pl;
+    ph.x = h[0] | ((unsigned)h[1] << 16); ph.y = h[2] | ((unsigned)h[3] << 16);
+    ph.z = h[4] | ((unsigned)h[5] << 16); ph.w = h[6] | ((unsigned)h[7] << 16);
+    pl.x = lo[0] | ((unsigned)lo[1] << 16); pl.y = lo[2] | ((unsigned)lo[3] << 16);
+    pl.z = lo[4] | ((unsigned)lo[5] << 16); pl.w = lo[6] | ((unsigned)lo[7] << 16);
+    bhi[t] = __builtin_bit_cast(kbf8, ph);
+    blo[t] = __builtin_bit_cast(kbf8, pl);
+  }
+
+  float g[2][16];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) g[t][i] = -__builtin_inff();
+  float tau[2] = {0.0f, 0.0f};
+  int cnt[2] = {0, 0};
+
+  for (int pass = 0; pass < 2; ++pass) {
+    const float *__restrict__ ct = ctab + (size_t)pass * s_pad;
+    uint4 ra0, ra1;
+    kf4 rc;
+    auto fetch = [&](int c) {
+      ra0 = panel[(size_t)c * (CH * 4) + tid];
+      ra1 = panel[(size_t)c * (CH * 4) + NT + tid];
+      if (tid < CH / 4) rc = *(const kf4 *)(ct + (size_t)c * CH + 4 * tid);
+    };
+    auto stash = [&](int b) {
+      abuf[b][tid] = ra0;
+      abuf[b][NT + tid] = ra1;
+      if (tid < CH / 4) *(kf4 *)&cbuf[b][4 * tid] = rc;
+    };
+    __syncthreads();            // the previous pass (and the sorted maxima in q) are done with shared memory
+    fetch(0);
+    stash(0);
+    __syncthreads();
+    for (int c = 0; c < nch; ++c) {
+      const int b = c & 1;
+      if (c + 1 < nch) fetch(c + 1);
+#pragma unroll
+      for (int tile = 0; tile < CH / 32; ++tile) {
+        const kbf8 ahi = __builtin_bit_cast(kbf8, abuf[b][tile * 128 + l]);
+        const kbf8 alo = __builtin_bit_cast(kbf8, abuf[b][tile * 128 + 64 + l]);
+        kf16 C;
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          const kf4 c4 = *(const kf4 *)&cbuf[b][tile * 32 + 8 * g4 + 4 * kh];
+          C[4 * g4 + 0] = c4[0]; C[4 * g4 + 1] = c4[1]; C[4 * g4 + 2] = c4[2]; C[4 * g4 + 3] = c4[3];
+        }
+        const int j0 = c * CH + tile * 32 + 4 * kh;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          kf16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[t], C, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[t], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[t], acc, 0, 0, 0);
+          if (pass == 0) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) g[t][i] = fmaxf(g[t][i], acc[i]);
+          } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+              const bool hit = !(acc[i] < tau[t]);
+              if (__any(hit)) {
+                if (hit) {
+                  if (cnt[t] < QC) q[(cnt[t] * 2 + kh) * PB + w * 64 + t * 32 + col] = (unsigned short)(j0 + 8 * (i >> 2) + (i & 3));
+                  ++cnt[t];
+                }
+              }
+            }
+          }
+        }
+      }
+      if (c + 1 < nch) stash(b ^ 1);
+      __syncthreads();
+    }
+    if (pass == 0) {
+      // tau: the r-th largest of the point's 32 group maxima, less the point's share of the error budget (twice: once for
+      // the bounds of pass 1, once for the test of pass 2)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        sort_desc<16>(g[t]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) sg[tid * 17 + i] = g[t][i];
+        __syncthreads();
+        float m = __builtin_inff();
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+          if (i < r) m = fminf(m, fmaxf(g[t][i], sg[(tid ^ 32) * 17 + (r - 1 - i)]));
+        }
+        tau[t] = off[t] ? __builtin_inff() : m - KNN_SCREEN_MU * xxf[t];
+        __syncthreads();
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) qcnt[kh * PB + w * 64 + t * 32 + col] = off[t] ? QC + 1 : cnt[t];
+  __syncthreads();
+
+  // ---- exact: lane = point
+  long i = base + tid;
+  const bool live = i < n;
+  if (!live) i = n - 1;
+  double x[DP];
+#pragma unroll
+  for (int k = 0; k < DP; ++k) x[k] = (k < d) ? X[(size_t)k * ldx + i] : 0.0;
+  double xx = x[0] * x[0];
+#pragma unroll
+  for (int k = 1; k < DP; ++k) xx = __builtin_fma(x[k], x[k], xx);  // zero padding adds exactly 0
+  int c0 = qcnt[tid], c1 = qcnt[PB + tid];
+  const bool rescan = c0 > QC || c1 > QC;
+  if (rescan) { c0 = 0; c1 = 0; }
+  TopList<RCAP> top;
+  top.init(r);
+  auto chain = [&](const double (&xa)[DP], double xxa, int j) {
+    const double *u = Ut + (size_t)j * DP;
+    double uk[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) uk[k] = u[k];
+    double acc = xa[0] * uk[0];
+#pragma unroll
+    for (int k = 1; k < DP; ++k) acc = __builtin_fma(xa[k], uk[k], acc);
+    return __builtin_fma(-2.0, acc, xxa) + uu[j];
+  };
+  {
+    const int ctot = c0 + c1;
+    for (int e = 0; __any(e < ctot); ++e) {
+      if (e < ctot) {
+        const int hh = e < c0 ? 0 : 1;
+        const int ee = e < c0 ? e : e - c0;
+        const int j = q[(ee * 2 + hh) * PB + tid];
+        const double D = chain(x, xx, j);
+        if (D < __builtin_inf() && top.before(D, j, RCAP - 1)) top.insert_lex(D, j);
+      }
+    }
+  }
+  if (live && !rescan) {
+#pragma unroll
+    for (int k = 0; k < RCAP; ++k) {
+      const int slot = k - (RCAP - r);
+      if (slot >= 0) {
+        const int bj_ = top.bi[k];     // see knn_kernel: never let the sentinel out
+        idx_out[(size_t)slot * ldo + i] = ((unsigned)bj_ < (unsigned)s) ? bj_ : slot;
+        if (dist_out) dist_out[(size_t)slot * ldo + i] = top.bd[k];
+      }
+    }
+  }
+
+  // ---- points the screen left alone: the wave scans all anchors for one of them at a time
+  unsigned long long todo = __ballot(rescan && live);
+  while (todo) {
+    const int p = __ffsll((long long)todo) - 1;
+    todo &= todo - 1;
+    double xp[DP];
+#pragma unroll
+    for (int k = 0; k < DP; ++k) xp[k] = __shfl(x[k], p);
+    const double xxp = __shfl(xx, p);
+    const long ip = base + w * 64 + p;
+    top.init(r);
+    for (int j = l; j < s; j += 64) {
+      const double D = chain(xp, xxp, j);
+      if (D < __builtin_inf() && top.before(D, j, RCAP - 1)) top.insert_lex(D, j);
+    }
+    int head = 0;                       // entries of my list already handed out
+    for (int slot = 0; slot < r; ++slot) {
+      double v = __builtin_inf();
+      int vj = 0x7fffffff;
+#pragma unroll
+      for (int k = 0; k < RCAP; ++k)
+        if (k == RCAP - r + head) { v = top.bd[k]; vj = top.bi[k]; }
+      double mv = v;
+      int mj = vj;
+#pragma unroll
+      for (int o = 32; o >= 1; o >>= 1) {
+        const double ov = __shfl_xor(mv, o);
+        const int oj = __shfl_xor(mj, o);
+        if (ov < mv || (ov == mv && oj < mj)) { mv = ov; mj = oj; }
+      }
+      const bool found = mv < __builtin_inf();
+      if (found && v == mv && vj == mj) ++head;
+      if (l == 0) {
+        idx_out[(size_t)slot * ldo + ip] = found ? mj : slot;
+        if (dist_out) dist_out[(size_t)slot * ldo + ip] = mv;
       }
     }
   }
@@ -477,6 +816,15 @@ static int launch_knn(hipStream_t st, const double *dX, int n, int ldx, int d, c
   return check_launch("knn_kernel");
 }
 
+template <int DP, int RCAP>
+static int launch_knn_screen(hipStream_t st, const double *dX, int n, int ldx, int d, const double *dUt,
+                             const double *duu, int s, int r, int *d_idx, double *d_dist, int ldo) {
+  ProfScope ps("knn_kernel", st, 2.0 * (double)n * (double)s * (double)d);
+  hipLaunchKernelGGL((knn_screen_kernel<DP, RCAP>), dim3(ceil_div(n, 256)), dim3(256), 0, st, dX, n, ldx, d, dUt, duu, s,
+                     r, d_idx, d_dist, ldo);
+  return check_launch("knn_screen_kernel");
+}
+
 }  // namespace flgp
 
 using namespace flgp;
@@ -490,15 +838,16 @@ extern "C" int flgp_dev_anchor_dpad(int d) {
   return -1;
 }
 
-// rows of the padded anchor panel: s rounded up to the kernel's anchor tile
-extern "C" int flgp_dev_anchor_rows(int s) { return (s + 127) / 128 * 128; }
+// rows to allocate for the anchor panel (Ut: rows x dpad doubles, uu: rows doubles): s rounded up to the kernels' anchor
+// tile, and as much again for the screening copy behind it (anchor_prep_kernel)
+extern "C" int flgp_dev_anchor_rows(int s) { return 2 * anchor_pad_rows(s); }
 
 extern "C" int flgp_dev_anchor_prep(void *stream, const double *dU, int s, int ldu, int d, double *dUt,
                                     double *duu) {
   const int dpad = flgp_dev_anchor_dpad(d);
   FLGP_REQUIRE(dpad > 0 && d >= 1, "k-NN kernels are built for 1 <= d <= %d (got %d)", FLGP_DMAX, d);
   FLGP_REQUIRE(s >= 1 && ldu >= s, "anchor_prep: need s >= 1 and ldu >= s");
-  const int s_pad = flgp_dev_anchor_rows(s);
+  const int s_pad = anchor_pad_rows(s);
   hipLaunchKernelGGL(anchor_prep_kernel, dim3(ceil_div(s_pad, 256)), dim3(256), 0, (hipStream_t)stream, dU, s,
                      s_pad, ldu, d, dpad, dUt, duu);
   return check_launch("anchor_prep_kernel");
@@ -552,6 +901,14 @@ extern "C" int flgp_dev_knn(void *stream, const double *dX, int n, int ldx, int 
   // d = 64 11.4 vs 18.8 ms, d = 32 5.4 vs 5.8 ms); at d <= 16 the selection is the larger half of either
   // kernel and the VALU kernel's three waves per SIMD hide its latencies better (d = 16: 6.7 vs 6.0 ms
   // per 1e6 points).  knn_mfma = 1 / 0 forces one or the other.
+  // d <= 16, r <= 16, enough anchors for 32 groups of them: the matrix-core screen (knn_screen = 0 switches it off)
+  if ((dpad == 8 || dpad == 16) && r <= 16 && s >= 512 && s < 65536 && tuning("knn_screen", 1) &&
+      tuning("knn_mfma", -1) < 0 && variant == 0) {
+#define KNN_SCREEN_CASE(DPv, RCv) if (dpad == DPv && rcap == RCv) return launch_knn_screen<DPv, RCv>(KNN_ARGS);
+    KNN_SCREEN_CASE(8, 4) KNN_SCREEN_CASE(8, 8) KNN_SCREEN_CASE(8, 16)
+    KNN_SCREEN_CASE(16, 4) KNN_SCREEN_CASE(16, 8) KNN_SCREEN_CASE(16, 16)
+#undef KNN_SCREEN_CASE
+  }
   const int use_mfma = tuning("knn_mfma", -1);
   if (use_mfma == 1 || (use_mfma < 0 && dpad >= 32)) {
 #define KNN_MFMA_CASE(DPv, RCv) if (dpad == DPv && rcap == RCv) return launch_knn_mfma<DPv, RCv>(KNN_ARGS);

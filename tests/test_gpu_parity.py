@@ -104,6 +104,68 @@ def test_knn_one_neighbour_kernels_bit_exact(oracle, variant):
         L.flgp_set_tuning(b"knn_nn1_variant", 0)
 
 
+def _knn_equal(oracle, X, U, r):
+    res = api.KNN_cpp(X, U, r, output=True)
+    oi, od = oracle.knn(X, U, r, output=True)
+    np.testing.assert_array_equal(res["ind_knn"], oi)
+    order = np.argsort(oi, axis=1, kind="stable")
+    np.testing.assert_array_equal(res["distances_sp"].data.reshape(X.shape[0], r), np.take_along_axis(od, order, axis=1))
+
+
+@pytest.mark.parametrize("n,d,s,r,seed", [(3000, 16, 700, 10, 0), (2500, 5, 512, 4, 1), (2999, 8, 2000, 16, 2),
+                                           (5700, 12, 5000, 7, 3), (1100, 9, 640, 2, 4), (1257, 16, 1024, 13, 5)])
+def test_knn_screened_kernel_random(oracle, n, d, s, r, seed):
+    """5 <= d <= 16, r <= 16, s >= 512 runs the kernel that screens anchors on the matrix cores in bf16 pieces and
+    evaluates the exact chain only for what is left: indices and distances stay the oracle's, bit for bit."""
+    X, U0, _ = make_case(n, d, s, r, seed=4242 + seed, with_sizes=False)
+    _knn_equal(oracle, X, U0, r)
+
+
+def test_knn_screened_kernel_where_the_screen_has_no_say(oracle):
+    """Everything the screen cannot decide goes to exact arithmetic alone: far-off data (the error budget is relative
+    to |x|^2 + |u|^2, so nearly every anchor stays a candidate), tiny and huge scales, points at the origin, huge
+    anchors, more duplicates of one anchor than a candidate queue holds, lattices of exact ties."""
+    rng = np.random.default_rng(99)
+    n, d, s, r = 1500, 16, 900, 10
+    X = rng.normal(size=(n, d)); U = X[rng.choice(n, s, replace=False)] + 0.05 * rng.normal(size=(s, d))
+    _knn_equal(oracle, X + 1.0e4, U + 1.0e4, r)                 # offset: queues overflow, whole-wave scans
+    _knn_equal(oracle, X * 1e-12, U * 1e-12, r)
+    _knn_equal(oracle, X * 1e-17, U * 1e-17, r)                 # |x|^2 below 1e-30
+    _knn_equal(oracle, X * 1e9, U * 1e9, r)
+    _knn_equal(oracle, X * 1e17, U * 1e17, r)                   # |x|^2 above 1e30
+    Xs = X.copy(); Us = U.copy()
+    Xs[::7] = 0.0; Xs[3::11] *= 1e-20; Xs[5::13] *= 1e25; Xs[11] = 1e140
+    Us[::9] *= 1e22; Us[4] = 0.0; Us[17] = 1e140
+    _knn_equal(oracle, Xs, Us, r)
+    Ud = U.copy(); Ud[100:260] = Ud[100]; Ud[300:340] = Ud[7]    # 160 and 40 copies of one anchor
+    _knn_equal(oracle, X, Ud, r)
+    _knn_equal(oracle, np.vstack([X, Ud[100:101], Ud[7:8]]), Ud, 16)
+    g = np.arange(-3, 4, dtype=float)                            # 7^3 = 343 lattice points twice: exact ties everywhere
+    L3 = np.array([[a, b, c, 0, 0] for a in g for b in g for c in g])
+    Ul = np.vstack([L3, L3])
+    Xl = np.vstack([L3[::5] + 0.5, L3[::7], rng.integers(-3, 4, size=(300, 5)) * 0.5])
+    for rr in (3, 8, 16):
+        _knn_equal(oracle, Xl, Ul, rr)
+
+
+def test_knn_screened_kernel_is_the_other_kernels_result_at_size(oracle):
+    """n = 2e5 points against s = 5000 anchors (the anchor count of BASELINE configs[2]): screened and unscreened
+    kernels return the same bits."""
+    from flgp_amd import _lib
+    L = _lib.lib()
+    n, d, s, r = 200000, 16, 5000, 10
+    X, U0, _ = make_case(n, d, s, r, seed=8, with_sizes=False)
+    a = api.KNN_cpp(X, U0, r, output=True)
+    try:
+        L.flgp_set_tuning(b"knn_screen", 0)
+        b = api.KNN_cpp(X, U0, r, output=True)
+    finally:
+        L.flgp_set_tuning(b"knn_screen", 1)
+    np.testing.assert_array_equal(a["ind_knn"], b["ind_knn"])
+    np.testing.assert_array_equal(a["distances_sp"].data, b["distances_sp"].data)
+    np.testing.assert_array_equal(a["distances_sp"].indices, b["distances_sp"].indices)
+
+
 def test_knn_single_point(oracle):
     rng = np.random.default_rng(4)
     X = rng.normal(size=(1, 16)); U = rng.normal(size=(300, 16))
