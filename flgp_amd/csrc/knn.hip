@@ -22,8 +22,8 @@
 
 namespace flgp {
 
-// rows of the fp64 panel: s rounded up to the kernels' anchor tile
-__host__ __device__ inline int anchor_pad_rows(int s) { return (s + 127) / 128 * 128; }
+// rows of the fp64 panel: s rounded up to the largest anchor tile of the kernels (the screen's 256; the others step by 128)
+__host__ __device__ inline int anchor_pad_rows(int s) { return (s + 255) / 256 * 256; }
 
 // ---- the screening copy of the anchors (knn_screen_kernel) ----
 // Behind the fp64 panel (rows_pad x dpad doubles at Ut, |u|^2 at uu) sits a copy for the matrix-core screen: every
@@ -31,8 +31,8 @@ __host__ __device__ inline int anchor_pad_rows(int s) { return (s + 127) / 128 *
 // A operands -- per tile of 32 anchors 2 KB: hi[khalf 2][anchor 32][8], then lo the same -- and two tables of
 // accumulator start values, C1_j = -(|u_j|^2 / 2)(1 + mu) and C2_j = -(|u_j|^2 / 2)(1 - mu) (rows_pad floats each, at
 // uu + rows_pad).  Anchors the screen has no say about (|u|^2 above 1e30 or not finite) get a zero row, C1 = -3e38 (never
-// a bound) and C2 = +3e38 (always a candidate); padding rows C1 = C2 = -3e38.  Written for dpad = 8 and 16 only;
-// flgp_dev_anchor_rows() hands out room for it.
+// a bound) and C2 = +3e38 (always a candidate); padding rows C1 = C2 = -3e38.  Written for dpad <= 16 (64 B per
+// anchor whatever dpad: two rows of the narrowest fp64 panel); flgp_dev_anchor_rows() hands out room for it.
 constexpr float KNN_SCREEN_MU = 1.220703125e-4f;   // 2^-13, see knn_screen_kernel
 constexpr float KNN_SCREEN_BIG = 3.0e38f;
 __device__ __host__ inline const unsigned short *screen_panel(const double *Ut, int s, int dpad) {
@@ -55,7 +55,7 @@ __global__ void anchor_prep_kernel(const double *__restrict__ U, int s, int s_pa
                                    double *__restrict__ Ut, double *__restrict__ uu) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= s_pad) return;
-  const bool screen = dpad == 8 || dpad == 16;
+  const bool screen = dpad <= 16;
   unsigned short *tile = (unsigned short *)(Ut + (size_t)s_pad * dpad) + (size_t)(j >> 5) * 1024 + (j & 31) * 8;
   float *c1 = (float *)(uu + s_pad), *c2 = c1 + s_pad;
   double acc = 0.0;
@@ -295,6 +295,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const double *__restrict__ X, 
 typedef __bf16 kbf8 __attribute__((ext_vector_type(8)));
 typedef float kf16 __attribute__((ext_vector_type(16)));
 typedef float kf4 __attribute__((ext_vector_type(4)));
+typedef float kf2 __attribute__((ext_vector_type(2)));
 constexpr int KNN_SCREEN_QC = 32;         // candidates per (point, half)
 
 template <int N>
@@ -317,14 +318,111 @@ __device__ __forceinline__ void sort_desc(float (&v)[N]) {   // bitonic network,
   }
 }
 
-template <int DP, int RCAP>
+// One sweep of the screen over all anchors.  PASS 0 keeps the running maximum of every accumulator slot (g), PASS 1
+// queues the anchors at or above the point's threshold.  Per tile of 32 anchors and per 32-point half t of the wave:
+// three MFMAs, the two halves' chains interleaved, the next tile's operands on their way from LDS meanwhile.
+// The VALU side works on packed differences: acc + 0 (PASS 0) makes the value a known-canonical float for one v_max_f32
+// per slot; acc - tau (PASS 1) turns "at or above the threshold" into a clear sign bit, so four slots are ruled out by
+// one v_max_i32 + v_max3_i32 on the bit patterns.
+template <int PASS, int CH, int QC, int PB, int DBG = 0>
+__device__ __forceinline__ void screen_sweep(const uint4 *__restrict__ panel, const float *__restrict__ ct, int nch,
+                                             uint4 (&abuf)[2][CH * 4], float (&cbuf)[2][CH], unsigned short *q,
+                                             const kbf8 (&bhi)[2], const kbf8 (&blo)[2], float (&g)[2][16],
+                                             const float (&tau)[2], int (&cnt)[2], int tid) {
+  constexpr int NT = 256, TPC = CH / 32, PER = CH * 4 / NT;
+  const int l = tid & 63, kh = l >> 5, w = tid >> 6, col = l & 31;
+  // chunk c of the panel and of the start values into buffer b, by LDS-DMA: each wave-instruction lands 64 x 16 B
+  // contiguously at its (wave-uniform) destination, which is exactly the panel's order; no registers held meanwhile
+  auto fetch = [&](int c, int b) {
+#pragma unroll
+    for (int e = 0; e < PER; ++e)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(panel + (size_t)c * (CH * 4) + e * NT + tid),
+                                       (__attribute__((address_space(3))) void *)&abuf[b][e * NT + w * 64], 16, 0, 0);
+    if (w == 0)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(ct + (size_t)c * CH + 4 * l),
+                                       (__attribute__((address_space(3))) void *)&cbuf[b][0], 16, 0, 0);
+  };
+  auto operands = [&](int b, int tile, kbf8 &h, kbf8 &lo, kf16 &Cv) {
+    h = __builtin_bit_cast(kbf8, abuf[b][tile * 128 + l]);
+    lo = __builtin_bit_cast(kbf8, abuf[b][tile * 128 + 64 + l]);
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+      const kf4 c4 = *(const kf4 *)&cbuf[b][tile * 32 + 8 * g4 + 4 * kh];
+      Cv[4 * g4 + 0] = c4[0]; Cv[4 * g4 + 1] = c4[1]; Cv[4 * g4 + 2] = c4[2]; Cv[4 * g4 + 3] = c4[3];
+    }
+  };
+  auto products = [&](const kbf8 &h, const kbf8 &lo, const kf16 &Cv, kf16 (&acc)[2]) {
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h, bhi[0], Cv, 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h, bhi[1], Cv, 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h, blo[0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(h, blo[1], acc[1], 0, 0, 0);
+    acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo, bhi[0], acc[0], 0, 0, 0);
+    acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(lo, bhi[1], acc[1], 0, 0, 0);
+  };
+  auto digest = [&](const kf16 (&acc)[2], int j0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if constexpr (PASS == 0) {
+#pragma unroll
+        for (int i = 0; i < ((DBG & 1) ? 1 : 16); ++i) g[t][i] = fmaxf(g[t][i], acc[t][i] + 0.0f);   // + 0: a float the compiler knows canonical
+      } else {
+        char *qp = (char *)(q + kh * PB + w * 64 + t * 32 + col);
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+          int iv[4];
+#pragma unroll
+          for (int i = 0; i < 4; ++i) iv[i] = __float_as_int(acc[t][4 * g4 + i] - tau[t]);
+          const int m = max(max(max(iv[0], iv[1]), iv[2]), iv[3]);
+          if (__ballot(m >= 0)) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+              if (iv[i] >= 0) {       // cnt counts in bytes of queue stride; past QC entries: overwritten, and counted
+                *(unsigned short *)(qp + (cnt[t] & ((QC - 1) * 4 * PB))) = (unsigned short)(j0 + 8 * g4 + i);
+                cnt[t] += 4 * PB;
+              }
+            }
+          }
+        }
+      }
+    }
+  };
+  __syncthreads();            // whoever used the shared buffers before is done with them
+  fetch(0, 0);
+  __syncthreads();            // (waits for the DMA, then the barrier)
+  for (int c = 0; c < nch; ++c) {
+    const int b = c & 1;
+    if (c + 1 < nch) fetch(c + 1, b ^ 1);     // the other buffer: everyone passed the barrier behind its last reader
+    // tile k + 1 multiplies while tile k is digested; the operands of tile k + 2 are on their way from LDS
+    kbf8 h0, l0, h1, l1;
+    kf16 C0, C1;
+    kf16 accA[2], accB[2];
+    operands(b, 0, h0, l0, C0);
+    operands(b, 1, h1, l1, C1);
+    products(h0, l0, C0, accA);
+#pragma unroll 1
+    for (int tile = 0; tile < TPC; tile += 2) {
+      const int j0 = c * CH + tile * 32 + 4 * kh;
+      if (!(DBG & 2)) operands(b, tile + 2 < TPC ? tile + 2 : tile, h0, l0, C0);
+      products(h1, l1, C1, accB);
+      digest(accA, j0);
+      if (!(DBG & 2)) operands(b, tile + 3 < TPC ? tile + 3 : tile, h1, l1, C1);
+      products(h0, l0, C0, accA);          // past the chunk's last tile: a repeat nobody reads (no branch in the pipeline)
+      digest(accB, j0 + 32);
+    }
+    __syncthreads();
+  }
+}
+
+template <int DP, int RCAP, int DBG = 0>
 __global__ __launch_bounds__(256, 2) void knn_screen_kernel(const double *__restrict__ X, int n, int ldx, int d,
-                                                         const double *__restrict__ Ut, const double *__restrict__ uu,
-                                                         int s, int r, int *__restrict__ idx_out,
-                                                         double *__restrict__ dist_out, int ldo) {
-  constexpr int NT = 256, PB = 256, CH = 128, QC = KNN_SCREEN_QC;
-  static_assert(DP == 8 || DP == 16, "the screen panel is written for dpad 8 and 16");
-  __shared__ uint4 abuf[2][CH * 4];                 // 128 anchors x 64 B
+                                                            const double *__restrict__ Ut, const double *__restrict__ uu,
+                                                            int s, int r, int *__restrict__ idx_out,
+                                                            double *__restrict__ dist_out, int ldo, int stop_after) {
+  constexpr int NT = 256, PB = 256, CH = 256, QC = KNN_SCREEN_QC;
+  static_assert(DP == 4 || DP == 8 || DP == 16, "the screen panel is written for dpad 4, 8 and 16");
+  static_assert(CH == 256, "one 1 KB LDS-DMA moves a chunk's start values");
+  static_assert((QC & (QC - 1)) == 0, "queue slots wrap by masking");
+  __shared__ uint4 abuf[2][CH * 4];                 // CH anchors x 64 B
   __shared__ __attribute__((aligned(16))) float cbuf[2][CH];
   __shared__ __attribute__((aligned(16))) unsigned short q[QC * 2 * PB];   // [entry][half][point]; first the sorted maxima
   __shared__ int qcnt[2 * PB];
@@ -333,12 +431,12 @@ __global__ __launch_bounds__(256, 2) void knn_screen_kernel(const double *__rest
 
   const int tid = threadIdx.x, w = tid >> 6, l = tid & 63, kh = l >> 5, col = l & 31;
   const long base = (long)blockIdx.x * PB;
-  const int s_pad = anchor_pad_rows(s);
-  const int nch = s_pad / CH;
+  const int s_pad = anchor_pad_rows(s);             // a multiple of 128: the last chunk may be half padding rows ...
+  const int nch = (s_pad + CH - 1) / CH;            // ... or, past s_pad, whatever the tables hold behind them: see below
   const uint4 *__restrict__ panel = (const uint4 *)screen_panel(Ut, s, DP);
   const float *__restrict__ ctab = screen_cinit(uu, s);
 
-  // ---- the points as B operands: lane = (point col of tile t, coordinates 8 kh .. 8 kh + 7)
+  // ---- the points as B operands: lane = (point col of half t, coordinates 8 kh .. 8 kh + 7)
   kbf8 bhi[2], blo[2];
   float xxf[2];
   bool off[2];                                      // the screen has no say about this point
@@ -380,87 +478,32 @@ __global__ __launch_bounds__(256, 2) void knn_screen_kernel(const double *__rest
   float tau[2] = {0.0f, 0.0f};
   int cnt[2] = {0, 0};
 
-  for (int pass = 0; pass < 2; ++pass) {
-    const float *__restrict__ ct = ctab + (size_t)pass * s_pad;
-    uint4 ra0, ra1;
-    kf4 rc;
-    auto fetch = [&](int c) {
-      ra0 = panel[(size_t)c * (CH * 4) + tid];
-      ra1 = panel[(size_t)c * (CH * 4) + NT + tid];
-      if (tid < CH / 4) rc = *(const kf4 *)(ct + (size_t)c * CH + 4 * tid);
-    };
-    auto stash = [&](int b) {
-      abuf[b][tid] = ra0;
-      abuf[b][NT + tid] = ra1;
-      if (tid < CH / 4) *(kf4 *)&cbuf[b][4 * tid] = rc;
-    };
-    __syncthreads();            // the previous pass (and the sorted maxima in q) are done with shared memory
-    fetch(0);
-    stash(0);
+  screen_sweep<0, CH, QC, PB, DBG>(panel, ctab, nch, abuf, cbuf, q, bhi, blo, g, tau, cnt, tid);
+  // tau: the r-th largest of the point's 32 group maxima, less the point's share of the error budget (twice: once for
+  // the bounds of pass 1, once for the test of pass 2)
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    sort_desc<16>(g[t]);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) sg[tid * 17 + i] = g[t][i];
     __syncthreads();
-    for (int c = 0; c < nch; ++c) {
-      const int b = c & 1;
-      if (c + 1 < nch) fetch(c + 1);
+    float m = __builtin_inff();
 #pragma unroll
-      for (int tile = 0; tile < CH / 32; ++tile) {
-        const kbf8 ahi = __builtin_bit_cast(kbf8, abuf[b][tile * 128 + l]);
-        const kbf8 alo = __builtin_bit_cast(kbf8, abuf[b][tile * 128 + 64 + l]);
-        kf16 C;
-#pragma unroll
-        for (int g4 = 0; g4 < 4; ++g4) {
-          const kf4 c4 = *(const kf4 *)&cbuf[b][tile * 32 + 8 * g4 + 4 * kh];
-          C[4 * g4 + 0] = c4[0]; C[4 * g4 + 1] = c4[1]; C[4 * g4 + 2] = c4[2]; C[4 * g4 + 3] = c4[3];
-        }
-        const int j0 = c * CH + tile * 32 + 4 * kh;
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          kf16 acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, bhi[t], C, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ahi, blo[t], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(alo, bhi[t], acc, 0, 0, 0);
-          if (pass == 0) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) g[t][i] = fmaxf(g[t][i], acc[i]);
-          } else {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-              const bool hit = !(acc[i] < tau[t]);
-              if (__any(hit)) {
-                if (hit) {
-                  if (cnt[t] < QC) q[(cnt[t] * 2 + kh) * PB + w * 64 + t * 32 + col] = (unsigned short)(j0 + 8 * (i >> 2) + (i & 3));
-                  ++cnt[t];
-                }
-              }
-            }
-          }
-        }
-      }
-      if (c + 1 < nch) stash(b ^ 1);
-      __syncthreads();
+    for (int i = 0; i < 16; ++i) {
+      if (i < r) m = fminf(m, fmaxf(g[t][i], sg[(tid ^ 32) * 17 + (r - 1 - i)]));
     }
-    if (pass == 0) {
-      // tau: the r-th largest of the point's 32 group maxima, less the point's share of the error budget (twice: once for
-      // the bounds of pass 1, once for the test of pass 2)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        sort_desc<16>(g[t]);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) sg[tid * 17 + i] = g[t][i];
-        __syncthreads();
-        float m = __builtin_inff();
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-          if (i < r) m = fminf(m, fmaxf(g[t][i], sg[(tid ^ 32) * 17 + (r - 1 - i)]));
-        }
-        tau[t] = off[t] ? __builtin_inff() : m - KNN_SCREEN_MU * xxf[t];
-        __syncthreads();
-      }
-    }
+    tau[t] = off[t] ? __builtin_inff() : m - KNN_SCREEN_MU * xxf[t];
+    __syncthreads();
   }
+  if (stop_after == 1) { if (tau[0] + tau[1] == 12345.0f) idx_out[0] = 0; return; }
+  screen_sweep<1, CH, QC, PB>(panel, ctab + s_pad, nch, abuf, cbuf, q, bhi, blo, g, tau, cnt, tid);
+  if (stop_after == 2) { if (cnt[0] + cnt[1] == 123456) idx_out[0] = 0; return; }
 #pragma unroll
-  for (int t = 0; t < 2; ++t) qcnt[kh * PB + w * 64 + t * 32 + col] = off[t] ? QC + 1 : cnt[t];
+  for (int t = 0; t < 2; ++t) qcnt[kh * PB + w * 64 + t * 32 + col] = off[t] ? QC + 1 : cnt[t] / (4 * PB);
   __syncthreads();
 
-  // ---- exact: lane = point
+  // ---- exact: lane = point.  The two halves' queues are ascending in the anchor index: merged on the fly, the strict
+  // '<' insertion sees the anchors in the oracle's order.
   long i = base + tid;
   const bool live = i < n;
   if (!live) i = n - 1;
@@ -475,25 +518,43 @@ __global__ __launch_bounds__(256, 2) void knn_screen_kernel(const double *__rest
   if (rescan) { c0 = 0; c1 = 0; }
   TopList<RCAP> top;
   top.init(r);
-  auto chain = [&](const double (&xa)[DP], double xxa, int j) {
+  auto row = [&](int j, double (&uk)[DP], double &un) {
     const double *u = Ut + (size_t)j * DP;
-    double uk[DP];
 #pragma unroll
     for (int k = 0; k < DP; ++k) uk[k] = u[k];
+    un = uu[j];
+  };
+  auto chain = [&](const double (&xa)[DP], double xxa, const double (&uk)[DP], double un) {
     double acc = xa[0] * uk[0];
 #pragma unroll
     for (int k = 1; k < DP; ++k) acc = __builtin_fma(xa[k], uk[k], acc);
-    return __builtin_fma(-2.0, acc, xxa) + uu[j];
+    return __builtin_fma(-2.0, acc, xxa) + un;
   };
   {
     const int ctot = c0 + c1;
+    int p0 = 0, p1 = 0;
+    auto next = [&]() {          // the smaller head of the two queues (the lists are disjoint)
+      const int j0 = p0 < c0 ? (int)q[(p0 * 2 + 0) * PB + tid] : 0x7fffffff;
+      const int j1 = p1 < c1 ? (int)q[(p1 * 2 + 1) * PB + tid] : 0x7fffffff;
+      const bool first = j0 < j1;
+      p0 += first ? 1 : 0;
+      p1 += first ? 0 : 1;
+      return first ? j0 : j1;
+    };
+    double un[DP], unn = 0.0;
+    int jn = 0;
+    if (0 < ctot) jn = next();
+    row(jn, un, unn);
     for (int e = 0; __any(e < ctot); ++e) {
+      double uc[DP];
+#pragma unroll
+      for (int k = 0; k < DP; ++k) uc[k] = un[k];
+      const double ucn = unn;
+      const int j = jn;
+      if (e + 1 < ctot) { jn = next(); row(jn, un, unn); }     // on its way while this one is evaluated
       if (e < ctot) {
-        const int hh = e < c0 ? 0 : 1;
-        const int ee = e < c0 ? e : e - c0;
-        const int j = q[(ee * 2 + hh) * PB + tid];
-        const double D = chain(x, xx, j);
-        if (D < __builtin_inf() && top.before(D, j, RCAP - 1)) top.insert_lex(D, j);
+        const double D = chain(x, xx, uc, ucn);
+        if (D < top.thr()) top.insert(D, j);
       }
     }
   }
@@ -521,8 +582,10 @@ __global__ __launch_bounds__(256, 2) void knn_screen_kernel(const double *__rest
     const long ip = base + w * 64 + p;
     top.init(r);
     for (int j = l; j < s; j += 64) {
-      const double D = chain(xp, xxp, j);
-      if (D < __builtin_inf() && top.before(D, j, RCAP - 1)) top.insert_lex(D, j);
+      double uk[DP], un;
+      row(j, uk, un);
+      const double D = chain(xp, xxp, uk, un);
+      if (D < top.thr()) top.insert(D, j);
     }
     int head = 0;                       // entries of my list already handed out
     for (int slot = 0; slot < r; ++slot) {
@@ -820,8 +883,15 @@ template <int DP, int RCAP>
 static int launch_knn_screen(hipStream_t st, const double *dX, int n, int ldx, int d, const double *dUt,
                              const double *duu, int s, int r, int *d_idx, double *d_dist, int ldo) {
   ProfScope ps("knn_kernel", st, 2.0 * (double)n * (double)s * (double)d);
+  const int dbg = tuning("knn_screen_dbg", 0);
+  if constexpr (DP == 16 && RCAP == 16) {
+    if (dbg == 1) hipLaunchKernelGGL((knn_screen_kernel<DP, RCAP, 1>), dim3(ceil_div(n, 256)), dim3(256), 0, st, dX, n, ldx, d, dUt, duu, s, r, d_idx, d_dist, ldo, tuning("knn_screen_stop", 0));
+    if (dbg == 2) hipLaunchKernelGGL((knn_screen_kernel<DP, RCAP, 2>), dim3(ceil_div(n, 256)), dim3(256), 0, st, dX, n, ldx, d, dUt, duu, s, r, d_idx, d_dist, ldo, tuning("knn_screen_stop", 0));
+    if (dbg == 3) hipLaunchKernelGGL((knn_screen_kernel<DP, RCAP, 3>), dim3(ceil_div(n, 256)), dim3(256), 0, st, dX, n, ldx, d, dUt, duu, s, r, d_idx, d_dist, ldo, tuning("knn_screen_stop", 0));
+    if (dbg) return check_launch("knn_screen_kernel");
+  }
   hipLaunchKernelGGL((knn_screen_kernel<DP, RCAP>), dim3(ceil_div(n, 256)), dim3(256), 0, st, dX, n, ldx, d, dUt, duu, s,
-                     r, d_idx, d_dist, ldo);
+                     r, d_idx, d_dist, ldo, tuning("knn_screen_stop", 0));
   return check_launch("knn_screen_kernel");
 }
 
@@ -839,8 +909,8 @@ extern "C" int flgp_dev_anchor_dpad(int d) {
 }
 
 // rows to allocate for the anchor panel (Ut: rows x dpad doubles, uu: rows doubles): s rounded up to the kernels' anchor
-// tile, and as much again for the screening copy behind it (anchor_prep_kernel)
-extern "C" int flgp_dev_anchor_rows(int s) { return 2 * anchor_pad_rows(s); }
+// tile, and twice as much again for the screening copy behind it (anchor_prep_kernel)
+extern "C" int flgp_dev_anchor_rows(int s) { return 3 * anchor_pad_rows(s); }
 
 extern "C" int flgp_dev_anchor_prep(void *stream, const double *dU, int s, int ldu, int d, double *dUt,
                                     double *duu) {
@@ -902,9 +972,10 @@ extern "C" int flgp_dev_knn(void *stream, const double *dX, int n, int ldx, int 
   // kernel and the VALU kernel's three waves per SIMD hide its latencies better (d = 16: 6.7 vs 6.0 ms
   // per 1e6 points).  knn_mfma = 1 / 0 forces one or the other.
   // d <= 16, r <= 16, enough anchors for 32 groups of them: the matrix-core screen (knn_screen = 0 switches it off)
-  if ((dpad == 8 || dpad == 16) && r <= 16 && s >= 512 && s < 65536 && tuning("knn_screen", 1) &&
+  if (dpad <= 16 && r >= 2 && r <= 16 && s >= 512 && s < 65536 && tuning("knn_screen", 1) &&
       tuning("knn_mfma", -1) < 0 && variant == 0) {
 #define KNN_SCREEN_CASE(DPv, RCv) if (dpad == DPv && rcap == RCv) return launch_knn_screen<DPv, RCv>(KNN_ARGS);
+    KNN_SCREEN_CASE(4, 4) KNN_SCREEN_CASE(4, 8) KNN_SCREEN_CASE(4, 16)
     KNN_SCREEN_CASE(8, 4) KNN_SCREEN_CASE(8, 8) KNN_SCREEN_CASE(8, 16)
     KNN_SCREEN_CASE(16, 4) KNN_SCREEN_CASE(16, 8) KNN_SCREEN_CASE(16, 16)
 #undef KNN_SCREEN_CASE

@@ -113,9 +113,10 @@ def _knn_equal(oracle, X, U, r):
 
 
 @pytest.mark.parametrize("n,d,s,r,seed", [(3000, 16, 700, 10, 0), (2500, 5, 512, 4, 1), (2999, 8, 2000, 16, 2),
-                                           (5700, 12, 5000, 7, 3), (1100, 9, 640, 2, 4), (1257, 16, 1024, 13, 5)])
+                                           (5700, 12, 5000, 7, 3), (1100, 9, 640, 2, 4), (1257, 16, 1024, 13, 5),
+                                           (3000, 3, 700, 3, 6), (2000, 2, 1024, 5, 7), (1500, 4, 600, 16, 8), (900, 1, 513, 2, 9)])
 def test_knn_screened_kernel_random(oracle, n, d, s, r, seed):
-    """5 <= d <= 16, r <= 16, s >= 512 runs the kernel that screens anchors on the matrix cores in bf16 pieces and
+    """d <= 16, 2 <= r <= 16, s >= 512 runs the kernel that screens anchors on the matrix cores in bf16 pieces and
     evaluates the exact chain only for what is left: indices and distances stay the oracle's, bit for bit."""
     X, U0, _ = make_case(n, d, s, r, seed=4242 + seed, with_sizes=False)
     _knn_equal(oracle, X, U0, r)
