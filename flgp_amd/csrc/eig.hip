@@ -110,11 +110,11 @@ __device__ __forceinline__ unsigned long long mix64(unsigned long long z) {
 }
 
 // deterministic start block: uniform(-1,1) from a counter hash
-__global__ void eig_init_q_kernel(double *__restrict__ Q, int s, int b, int ldq) {
+__global__ void eig_init_q_kernel(double *__restrict__ Q, int s, int b, int ldq, unsigned long long stream) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long)s * b) return;
   const int i = (int)(e % s), j = (int)(e / s);
-  const unsigned long long h = mix64((unsigned long long)e * 2 + 0x5851F42D4C957F2Dull);
+  const unsigned long long h = mix64((unsigned long long)e * 2 + 0x5851F42D4C957F2Dull + stream * 0x9E3779B97F4A7C15ull);
   Q[(size_t)j * ldq + i] = ((double)(h >> 11) + 0.5) * (2.0 / 9007199254740992.0) - 1.0;
 }
 
@@ -409,6 +409,7 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
   double *Gc = Gm, *Gn = G2, *Wc = Wm, *Wn = W2;
   const double tol2 = tol * tol;
   int rotations = 0;
+  double max_sn = 0.0;                 // largest squared cosine between two columns rotated in this visit (leader lanes)
   for (int ls = 0; ls < local_sweeps; ++ls) {
     if (tid == 0) any_rot = 0;
     __syncthreads();
@@ -433,6 +434,7 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
           sn = (dl >= 0.0 ? ga : -ga) * (r1 * r2);
           ++rot_here;
           round_rot[rr % 3] = 1;
+          max_sn = __builtin_fmax(max_sn, (ga * ga) / (al * be));
         }
         cc[p] = cs; dd[p] = -sn; pr[p] = q;   // new_p = c old_p - s old_q
         cc[q] = cs; dd[q] = sn;  pr[q] = p;   // new_q = s old_p + c old_q
@@ -463,7 +465,10 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
     for (int e = tid; e < NLOC * NLOC; e += 1024) Wm[e] = Wc[e];
   }
   __syncthreads();
-  if (rotations) atomicAdd(&flags[0], rotations);
+  if (rotations) {
+    atomicAdd(&flags[0], rotations);
+    atomicMax(&flags[3], __float_as_int((float)__builtin_sqrt(max_sn) * 1.0000002f));   // >= 0: the bit patterns order like the values
+  }
   // ---- apply the accumulated rotation to the B panel, then to the V panel (same LDS buffer)
   apply_w();
   __syncthreads();
@@ -634,6 +639,8 @@ __global__ void embed_block_kernel(const double *__restrict__ Vg, int g, int K, 
 __global__ void jac_sweep_end_kernel(int *__restrict__ flags) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     if (flags[0] == 0) flags[1] = 1;
+    if (flags[2] < 8) flags[4 + flags[2]] = flags[3];   // largest cosine rotated in the sweep (a float's bits), kept for the log
+    flags[3] = 0;
     flags[2] += 1;       // sweeps run (only counts while not converged)
     flags[0] = 0;
   }
@@ -902,7 +909,7 @@ static int jacobi_run(hipStream_t st, int b, EigWork &w, std::vector<double> &h_
                   : p.nloc == 16 ? (const void *)jac_block_kernel<16> : (const void *)jac_round_kernel;
   if (p.lds > 48 * 1024)
     FLGP_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
-  FLGP_HIP(hipMemsetAsync(w.flags, 0, sizeof(int) * 3, st));
+  FLGP_HIP(hipMemsetAsync(w.flags, 0, sizeof(int) * 12, st));
   const bool to_convergence = sweep_limit < 0;
   const int max_sweeps = to_convergence ? 60 : sweep_limit;
   // rotate while |b_p . b_q| > tol |b_p||b_q|; a dot product of length b carries ~sqrt(b) eps of
@@ -933,6 +940,14 @@ static int jacobi_run(hipStream_t st, int b, EigWork &w, std::vector<double> &h_
   }
   hipLaunchKernelGGL(jac_values_kernel, dim3(b), dim3(256), 0, st, JB, JV, b, b, w.lam);
   FLGP_TRY(check_launch("jac_values_kernel"));
+  if (tuning("eig_verbose", 0) > 2) {
+    int hf[12];
+    FLGP_HIP(hipMemcpyAsync(hf, w.flags, sizeof(hf), hipMemcpyDeviceToHost, st));
+    FLGP_HIP(hipStreamSynchronize(st));
+    fprintf(stderr, "[flgp jacobi] b=%d sweeps=%d largest column cosine rotated, per sweep:", b, hf[2]);
+    for (int q = 0; q < hf[2] && q < 8; ++q) { float f; memcpy(&f, &hf[4 + q], 4); fprintf(stderr, " %.2e", f); }
+    fprintf(stderr, "\n");
+  }
   if (!to_host) return FLGP_OK;        // a fixed number of sweeps on the device: the eigenvalues stay in w.lam
   h_lam.resize(b);
   FLGP_HIP(hipMemcpyAsync(h_lam.data(), w.lam, sizeof(double) * b, hipMemcpyDeviceToHost, st));
@@ -1177,7 +1192,8 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     FLGP_TRY(check_launch("sym_scale_kernel"));
     double delta = 0.0;
     FLGP_TRY(dist_to_identity(w.T, &delta));
-    if (delta < 6.0) {  // |I - S|_F bounds the spectral norm from above, loosely: try, and watch it contract
+    if (delta < 0.1 * tuning("eig_ns_plain_below_x10", 45)) {  // |I - S|_F bounds the spectral norm from above, loosely: try, and watch it contract
+                                                              // (measured at configs[2]: 3.6 contracted, 5.7 did not)
       // well-conditioned block: S^-1/2 by the coupled Newton-Schulz iteration -- b x b MFMA GEMMs only
       //   M = (3 I - Z Y)/2,  Y <- Y M,  Z <- M Z ;  Y -> S^1/2, Z -> S^-1/2   (|I - S| < 1)
       double *Yc = w.T, *Zc = w.JV, *Mm = w.W, *Yn = w.JB, *Zn = w.X2;
@@ -1246,18 +1262,45 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
         FLGP_HIP(hipMemcpyAsync(Zc, w.Id, sizeof(double) * (size_t)b * b, hipMemcpyDeviceToDevice, st));
         double dm = 1.0;
         bool ok = false;
-        for (int k = 0; k < 72 && !ok; ++k) {
+        // Dynamically scaled steps (Chen & Chow 2014): with every singular value x of the iterate in [l, 1],
+        //   x <- (a / 2) x (3 - a^2 x^2),  a = sqrt(3 / (1 + l + l^2)),
+        // is the cubic that lifts the lower end the most, l <- (a / 2) l (3 - a^2 l^2) (x 2.6 per step while l is small,
+        // against 1.5 unscaled), and keeps [l, 1] inside itself.  l_0 is a guess: one that is too low costs a few steps,
+        // one that is too high leaves singular values behind that the unscaled steps below then pick up at their own pace.
+        // The step count follows from l alone, so the host is not asked until the end.
+        int kdyn = 0;
+        {
+          double ell = std::pow(10.0, -(double)tuning("eig_ns_ell0_exp", 5));
+          const int tail = tuning("eig_ns_tail", 2);
+          int after = 0;
+          while (kdyn < 60 && tuning("eig_ns_dynamic", 1)) {
+            const bool plain = ell > 1.0 - 1e-9;
+            if (plain && after++ >= tail) break;
+            const double a = plain ? 1.0 : std::sqrt(3.0 / (1.0 + ell + ell * ell));
+            FLGP_TRY(small_gemm(Zc, Yc, -0.5 * a * a * a, 1.5 * a, w.Id, Mm));
+            FLGP_TRY(small_gemm2(Yc, Mm, Yn, Mm, Zc, Zn));
+            std::swap(Yc, Yn);
+            std::swap(Zc, Zn);
+            ell = std::min(1.0, 0.5 * a * ell * (3.0 - a * a * ell * ell));
+            ++kdyn;
+          }
+          if (kdyn) {
+            FLGP_TRY(dist_to_identity(Mm, &dm));
+            ok = std::isfinite(dm) && dm < 1e-9;
+          }
+        }
+        for (int k = 0; k < 72 && !ok && std::isfinite(dm); ++k) {
           FLGP_TRY(small_gemm(Zc, Yc, -0.5, 1.5, w.Id, Mm));
           FLGP_TRY(small_gemm2(Yc, Mm, Yn, Mm, Zc, Zn));
           std::swap(Yc, Yn);
           std::swap(Zc, Zn);
-          if (k >= 8 && k % 3 == 2) {
+          if ((kdyn || k >= 8) && k % 3 == 2) {
             FLGP_TRY(dist_to_identity(Mm, &dm));
             if (!std::isfinite(dm)) break;
             ok = dm < 1e-9;
           }
         }
-        if (tuning("eig_verbose", 0) > 1) fprintf(stderr, "[flgp orth] scaled: delta=%.3e sigma=%.3e dm=%.2e %s\n", delta, sigma, dm, ok ? "ok" : "FAILED");
+        if (tuning("eig_verbose", 0) > 1) fprintf(stderr, "[flgp orth] scaled: delta=%.3e sigma=%.3e scaled steps=%d dm=%.2e %s\n", delta, sigma, kdyn, dm, ok ? "ok" : "FAILED");
         if (ok) {
           double zn = 0.0;   // |Z - I|_F^2 + 1 >= 1/x_min: an upper bound of cond(S / sigma)
           FLGP_TRY(dist_to_identity(Zc, &zn));
@@ -1301,7 +1344,8 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   //      iterates to convergence by itself, so once is enough).  Four s x b buffers rotate through the roles
   //      Q (orthonormal block) and three free ones.
   double *Q = w.Q, *F[3] = {w.Y, w.Yp, w.Z};
-  hipLaunchKernelGGL(eig_init_q_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, st, F[0], s, b, s);
+  hipLaunchKernelGGL(eig_init_q_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, st, F[0], s, b, s,
+                     (unsigned long long)tuning("eig_start_stream", 0));   // 0 = the documented start block; others: robustness runs
   FLGP_TRY(check_launch("eig_init_q_kernel"));
   // Rayleigh-Ritz on the random start block yields nothing but bounds, and poor ones (every Ritz value of a random
   // subspace sits near the mean eigenvalue); the span p(G) Q does not depend on the basis.  So the first filter runs
