@@ -275,8 +275,12 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
         stage_load(rb, ob, k2, kend, f2, tid);
       }
     }
+    // the last stage of a k range that is no multiple of GK holds zeros from kend on: its k steps of four that are all
+    // padding are skipped (K = 200: 2 of the 52 steps of a tile)
+    const int klim = kend - kof(si);
 #pragma unroll
     for (int kk = 0; kk < GK; kk += 4) {
+      if (kk >= klim) break;
       double fa[4], fb[4];
 #pragma unroll
       for (int mi = 0; mi < 4; ++mi) fa[mi] = As[(kk + fk) * GLD + wr + mi * 16 + fr];
