@@ -1405,6 +1405,32 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     const double amp = std::pow(10.0, (double)((it_ < 2) ? tuning("eig_amp_exp_early", 3) : tuning("eig_amp_exp", 8)));
     int m = (int)std::floor(std::acosh(amp) / std::acosh(std::max(g1, 1.0 + 1e-12)));
     fp.m = std::max(2, std::min(m, 40));
+    // Landing.  A filter of degree m contracts the residual of the K-th pair -- the slowest -- by 1 / T_m(g_K) ~ 2 exp(-m a),
+    // a = acosh(g_K), g_K the K-th Ritz value on the filter's own scale (measured at configs[2]: 0.0526 per iteration
+    // against 1 / T_8(1.1055) = 0.0526).  With the last measured residual that gives the iterations still needed at the
+    // capped degree, n0.  If a few degrees more per iteration save a whole iteration (orthonormalisation, Rayleigh-Ritz
+    // and its wait: ~1 ms) they are spent; if n0 iterations overshoot, the degree is lowered to what the tolerance needs.
+    // Without this the iteration on which the residual test is first met moves by one with perturbations of rounding
+    // size (10 or 11 iterations at configs[2], depending on the start block).
+    if (it_ >= 3 && tuning("eig_landing", 1) && rmax_prev > 0.0 && rmax_prev < 1e-2) {
+      const double gK = (theta[K - 1] - fp.c) / fp.e;
+      if (gK > 1.0 + 1e-9) {
+        const double a = std::acosh(gK), ln2 = 0.6931471805599453;
+        const double target = tol * 0.01 * (double)tuning("eig_landing_margin_pct", 40);
+        const double L = std::log(rmax_prev / target);
+        const double per0 = fp.m * a - ln2;
+        if (L > 0.0 && per0 > 0.0) {
+          const int n0 = std::max(1, (int)std::ceil(L / per0));
+          auto degree_for = [&](int n) { return (int)std::ceil((L / n + ln2) / a); };
+          int mm = degree_for(n0);                                  // <= fp.m by construction of n0
+          // (one iteration fewer at most, and three degrees more at most: with five or eight more per iteration the block
+          //  loses accuracy faster than the filter gains -- 14 and 15 iterations instead of 10)
+          if (n0 >= 2 && degree_for(n0 - 1) <= fp.m + tuning("eig_landing_boost", 3)) mm = degree_for(n0 - 1);
+          fp.m = std::max(2, std::min(mm, 40));
+          rate = std::min(0.5, std::max(1e-4, 2.0 * std::exp(-fp.m * a)));
+        }
+      }
+    }
     fp.sigma1 = fp.e / (top - fp.c);
     return fp;
   };

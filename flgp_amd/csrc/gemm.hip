@@ -19,18 +19,19 @@
 // host wrapper orients the problem (computing C^T = B^T A^T when C is column-major) such that
 // the memory-contiguous output dimension is always the kernel's column dimension.
 #include "common.h"
+#include <type_traits>
 
 namespace flgp {
 
 typedef double d4 __attribute__((ext_vector_type(4)));
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-constexpr int GB = 128;        // block tile (rows and cols)
+constexpr int GB = 128;        // block tile (rows and cols) of the large shapes; 64 where 128 leaves CUs idle (GBT below)
 constexpr int GK = 16;         // k depth per stage
 #ifndef GEMM_GLD_PAD
 #define GEMM_GLD_PAD 17
 #endif
-constexpr int GLD = GB + GEMM_GLD_PAD;   // padded LDS row stride (doubles)
+constexpr int gld_of(int gbt) { return gbt + GEMM_GLD_PAD; }   // padded LDS row stride (doubles)
 
 struct GemmArgs {
   int M, N, Kd;
@@ -68,16 +69,18 @@ __device__ __forceinline__ void store_wt_d2(double *p, d2 v) {
 // which is why the interior of the problem does not take it.
 enum { LOAD_GEN = 0, LOAD_RC = 1, LOAD_KC = 2 };
 
-__device__ __forceinline__ void tile_load_gen(double (&reg)[8], const double *__restrict__ base, long rs, long ks,
+template <int GBT>
+__device__ __forceinline__ void tile_load_gen(double (&reg)[GBT / 16], const double *__restrict__ base, long rs, long ks,
                                               int row0, int nrows, int k0, int kend, bool row_contig, int tid) {
+  constexpr int NR = GBT / 16, KPT = 256 / GBT;   // registers per thread; k values covered by the 256 threads at once
   if (row_contig) {
-    const int row = row0 + (tid & 127);
-    const int kb = tid >> 7;
+    const int row = row0 + (tid & (GBT - 1));
+    const int kb = tid / GBT;
     const bool rv = row < nrows;
     const double *pr = base + (size_t)(rv ? row : nrows - 1) * rs;
 #pragma unroll
-    for (int rep = 0; rep < 8; ++rep) {
-      const int k = k0 + kb + 2 * rep;
+    for (int rep = 0; rep < NR; ++rep) {
+      const int k = k0 + kb + KPT * rep;
       const bool kv = k < kend;
       const double v = pr[(size_t)(kv ? k : kend - 1) * ks];
       reg[rep] = (rv && kv) ? v : 0.0;
@@ -88,7 +91,7 @@ __device__ __forceinline__ void tile_load_gen(double (&reg)[8], const double *__
     const bool kv = k < kend;
     const double *pk = base + (size_t)(kv ? k : kend - 1) * ks;
 #pragma unroll
-    for (int rep = 0; rep < 8; ++rep) {
+    for (int rep = 0; rep < NR; ++rep) {
       const int row = row0 + rb + 16 * rep;
       const bool rv = row < nrows;
       const double v = pk[(size_t)(rv ? row : nrows - 1) * rs];
@@ -97,15 +100,17 @@ __device__ __forceinline__ void tile_load_gen(double (&reg)[8], const double *__
   }
 }
 
-__device__ __forceinline__ void tile_store_gen(const double (&reg)[8], double *__restrict__ lds, bool row_contig, int tid) {
+template <int GBT>
+__device__ __forceinline__ void tile_store_gen(const double (&reg)[GBT / 16], double *__restrict__ lds, bool row_contig, int tid) {
+  constexpr int NR = GBT / 16, KPT = 256 / GBT, GLD = gld_of(GBT);
   if (row_contig) {
-    const int row = tid & 127, kb = tid >> 7;
+    const int row = tid & (GBT - 1), kb = tid / GBT;
 #pragma unroll
-    for (int rep = 0; rep < 8; ++rep) lds[(kb + 2 * rep) * GLD + row] = reg[rep];
+    for (int rep = 0; rep < NR; ++rep) lds[(kb + KPT * rep) * GLD + row] = reg[rep];
   } else {
     const int k = tid & 15, rb = tid >> 4;
 #pragma unroll
-    for (int rep = 0; rep < 8; ++rep) lds[k * GLD + rb + 16 * rep] = reg[rep];
+    for (int rep = 0; rep < NR; ++rep) lds[k * GLD + rb + 16 * rep] = reg[rep];
   }
 }
 
@@ -118,17 +123,21 @@ struct Operand {
   const double *fast;   // per-thread pointer of the fast mappings at k = 0
 };
 
+// fast mappings, GBT rows x 16 k over 256 threads:
+//   RC: a thread takes rows 2 l, 2 l + 1 (l = tid % (GBT/2)) at k = tid / (GBT/2) + (512/GBT) rep, rep < GBT/32
+//   KC: a thread takes k = 2 (tid & 7), + 1 of row tid >> 3 + 32 rep, rep < GBT/32
+template <int GBT>
 __device__ __forceinline__ Operand make_operand(const double *base, long rs, long ks, int row0, int nrows, int tid) {
   Operand o;
   o.base = base; o.rs = rs; o.ks = ks; o.row0 = row0; o.nrows = nrows;
   o.row_contig = (rs == 1);
   o.mode = LOAD_GEN;
   o.fast = base;
-  const bool inside = row0 + GB <= nrows;
+  const bool inside = row0 + GBT <= nrows;
   const bool al16 = (((size_t)base) & 15) == 0;
   if (inside && al16 && rs == 1 && (ks & 1) == 0) {
     o.mode = LOAD_RC;
-    o.fast = base + (size_t)(row0 + 2 * (tid & 63)) + (size_t)(tid >> 6) * ks;
+    o.fast = base + (size_t)(row0 + 2 * (tid & (GBT / 2 - 1))) + (size_t)(tid / (GBT / 2)) * ks;
   } else if (inside && al16 && ks == 1 && (rs & 1) == 0) {
     o.mode = LOAD_KC;
     o.fast = base + (size_t)(row0 + (tid >> 3)) * rs + (size_t)(2 * (tid & 7));
@@ -137,58 +146,63 @@ __device__ __forceinline__ Operand make_operand(const double *base, long rs, lon
 }
 
 // stage [k0, k0 + GK) of the operand into registers; `full` = the stage lies inside [., kend)
-__device__ __forceinline__ void stage_load(double (&reg)[8], const Operand &o, int k0, int kend, bool full, int tid) {
+template <int GBT>
+__device__ __forceinline__ void stage_load(double (&reg)[GBT / 16], const Operand &o, int k0, int kend, bool full, int tid) {
+  constexpr int NP = GBT / 32, KS = 512 / GBT;     // 16-byte loads per thread; k step between them in the RC mapping
   if (full && o.mode == LOAD_RC) {
     const double *p = o.fast + (size_t)k0 * o.ks;
 #pragma unroll
-    for (int rep = 0; rep < 4; ++rep) {
-      const d2 v = *(const d2 *)(p + (size_t)(4 * rep) * o.ks);
+    for (int rep = 0; rep < NP; ++rep) {
+      const d2 v = *(const d2 *)(p + (size_t)(KS * rep) * o.ks);
       reg[2 * rep] = v[0];
       reg[2 * rep + 1] = v[1];
     }
   } else if (full && o.mode == LOAD_KC) {
     const double *p = o.fast + k0;
 #pragma unroll
-    for (int rep = 0; rep < 4; ++rep) {
+    for (int rep = 0; rep < NP; ++rep) {
       const d2 v = *(const d2 *)(p + (size_t)(32 * rep) * o.rs);
       reg[2 * rep] = v[0];
       reg[2 * rep + 1] = v[1];
     }
   } else if (o.mode == LOAD_RC) {
-    // the k tail of a row-contiguous operand keeps the wide mapping: k = k0 + (tid >> 6) + 4 rep is the same for
-    // all lanes of a wave, rows past kend read row kend - 1 (a valid address) and are zeroed
-    const int kq = k0 + (tid >> 6);
+    // the k tail of a row-contiguous operand keeps the wide mapping: k = k0 + tid / (GBT/2) + KS rep is the same for
+    // GBT/2 adjacent lanes, rows past kend read row kend - 1 (a valid address) and are zeroed
+    const int kt = tid / (GBT / 2);
+    const int kq = k0 + kt;
 #pragma unroll
-    for (int rep = 0; rep < 4; ++rep) {
-      const int k = kq + 4 * rep;
+    for (int rep = 0; rep < NP; ++rep) {
+      const int k = kq + KS * rep;
       const int kc = (k < kend) ? k : kend - 1;
-      const d2 v = *(const d2 *)(o.fast + (size_t)(kc - (tid >> 6)) * o.ks);   // o.fast sits at k = tid >> 6
+      const d2 v = *(const d2 *)(o.fast + (size_t)(kc - kt) * o.ks);   // o.fast sits at k = kt
       reg[2 * rep] = (k < kend) ? v[0] : 0.0;
       reg[2 * rep + 1] = (k < kend) ? v[1] : 0.0;
     }
   } else {
-    tile_load_gen(reg, o.base, o.rs, o.ks, o.row0, o.nrows, k0, kend, o.row_contig, tid);
+    tile_load_gen<GBT>(reg, o.base, o.rs, o.ks, o.row0, o.nrows, k0, kend, o.row_contig, tid);
   }
 }
 
-__device__ __forceinline__ void stage_store(const double (&reg)[8], double *__restrict__ lds, const Operand &o, bool full,
+template <int GBT>
+__device__ __forceinline__ void stage_store(const double (&reg)[GBT / 16], double *__restrict__ lds, const Operand &o, bool full,
                                             int tid) {
+  constexpr int NP = GBT / 32, KS = 512 / GBT, GLD = gld_of(GBT);
   if (o.mode == LOAD_RC) {      // (the tail stage of a row-contiguous operand uses this mapping too)
-    double *q = lds + (tid >> 6) * GLD + 2 * (tid & 63);
+    double *q = lds + (tid / (GBT / 2)) * GLD + 2 * (tid & (GBT / 2 - 1));
 #pragma unroll
-    for (int rep = 0; rep < 4; ++rep) {
-      q[(4 * rep) * GLD] = reg[2 * rep];
-      q[(4 * rep) * GLD + 1] = reg[2 * rep + 1];
+    for (int rep = 0; rep < NP; ++rep) {
+      q[(KS * rep) * GLD] = reg[2 * rep];
+      q[(KS * rep) * GLD + 1] = reg[2 * rep + 1];
     }
   } else if (full && o.mode == LOAD_KC) {
     double *q = lds + (2 * (tid & 7)) * GLD + (tid >> 3);
 #pragma unroll
-    for (int rep = 0; rep < 4; ++rep) {
+    for (int rep = 0; rep < NP; ++rep) {
       q[32 * rep] = reg[2 * rep];
       q[GLD + 32 * rep] = reg[2 * rep + 1];
     }
   } else {
-    tile_store_gen(reg, lds, o.row_contig, tid);
+    tile_store_gen<GBT>(reg, lds, o.row_contig, tid);
   }
 }
 
@@ -196,13 +210,18 @@ __device__ __forceinline__ void stage_store(const double (&reg)[8], double *__re
 // forms sustain 72-76 TFLOP/s in the bare inner loop -- scripts/ubench_inner.hip -- so the form with the
 // fewer operand reads stays.  Layout of the 4x4x4 form, probed on the device with scripts/probe_mfma4.hip:
 // A_b(i,k) in lane i + 4b + 16k, B_b(k,j) in lane j + 4b + 16k, D_b(i,j) in lane j + 4b + 16i.)
+// GBT = 128: the tile of the large shapes.  GBT = 64 (each wave a 32 x 32 sub-tile, 2 x 2 MFMA tiles): the solver's
+// s x b and b x b products, which have 80 and 4 tiles of 128 -- a quarter of the chip, or split-K planes and a reduction
+// launch to make up for it -- and 316 / 16 tiles of 64.
+template <int GBT>
 __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
+  constexpr int GB = GBT, GLD = gld_of(GBT), MI = GBT / 32, NR = GBT / 16;
   // two LDS stages: the tile of stage s+1 is written while stage s is being multiplied, one barrier per stage
   __shared__ double As2[2][GK * GLD];
   __shared__ double Bs2[2][GK * GLD];
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
-  const int wr = (wave >> 1) * 64, wc = (wave & 1) * 64;
+  const int wr = (wave >> 1) * (GBT / 2), wc = (wave & 1) * (GBT / 2);
 
   // XCD-aware tile order: consecutive block ids share an XCD every 8; give each XCD a band of tiles
   const int ntm = (g.M + GB - 1) / GB, ntn = (g.N + GB - 1) / GB;
@@ -233,46 +252,55 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   int ns = (kend - kbeg + GK - 1) / GK;
   if (ns < 0) ns = 0;
   auto kof = [&](int si) { return kbeg + si * GK; };
-  auto load_a = [&](double (&reg)[8], const Operand &o, int si, int k0, bool full) { stage_load(reg, o, k0, kend, full, tid); };
+  auto load_a = [&](double (&reg)[NR], const Operand &o, int si, int k0, bool full) { stage_load<GBT>(reg, o, k0, kend, full, tid); };
 
-  const Operand oa = make_operand(g.A, g.a_is, g.a_ks, row0, g.M, tid);
-  const Operand ob = make_operand(g.B, g.b_js, g.b_ks, col0, g.N, tid);
-  d4 acc[4][4];
+  const Operand oa = make_operand<GBT>(g.A, g.a_is, g.a_ks, row0, g.M, tid);
+  const Operand ob = make_operand<GBT>(g.B, g.b_js, g.b_ks, col0, g.N, tid);
+  d4 acc[MI][MI];
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi)
+  for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
+    for (int ni = 0; ni < MI; ++ni) acc[mi][ni] = d4{0.0, 0.0, 0.0, 0.0};
 
-  double ra[8], rb[8];
+  // Operand stages on their way: NS register sets.  While stage si is multiplied out of one LDS buffer, set (si + 1) % NS
+  // (stage si + 1, loaded NS stages ago) goes into the other buffer and is refilled with stage si + 1 + NS.  The 128-tile
+  // has registers for one set (two stages of flight: its 64 MFMAs per stage cover the latency); the 64-tile does 16 MFMAs
+  // per stage and, on the shapes it is used for, runs alone on its CU: three sets, four stages of flight.
+  constexpr int NS = (GBT == 64) ? 3 : 1;
+  double ra[NS][NR], rb[NS][NR];
   if (ns > 0) {
     const int k0 = kof(0);
     const bool f0 = k0 + GK <= kend;
-    load_a(ra, oa, 0, k0, f0);
-    stage_load(rb, ob, k0, kend, f0, tid);
-    stage_store(ra, As2[0], oa, f0, tid);
-    stage_store(rb, Bs2[0], ob, f0, tid);
-    if (ns > 1) {
-      const int k1 = kof(1);
-      const bool f1 = k1 + GK <= kend;
-      load_a(ra, oa, 1, k1, f1);
-      stage_load(rb, ob, k1, kend, f1, tid);
+    load_a(ra[0], oa, 0, k0, f0);
+    stage_load<GBT>(rb[0], ob, k0, kend, f0, tid);
+    stage_store<GBT>(ra[0], As2[0], oa, f0, tid);
+    stage_store<GBT>(rb[0], Bs2[0], ob, f0, tid);
+#pragma unroll
+    for (int j = 1; j <= NS; ++j) {
+      if (j < ns) {
+        const int kj = kof(j);
+        const bool fj = kj + GK <= kend;
+        load_a(ra[j % NS], oa, j, kj, fj);
+        stage_load<GBT>(rb[j % NS], ob, kj, kend, fj, tid);
+      }
     }
   }
   __syncthreads();
 
   const int fr = lane & 15, fk = lane >> 4;
   int cur = 0;
-  for (int si = 0; si < ns; ++si, cur ^= 1) {
+  auto step = [&](auto set_c, int si) {
+    constexpr int SET = decltype(set_c)::value;     // == (si + 1) % NS
     const double *As = As2[cur], *Bs = Bs2[cur];
-    if (si + 1 < ns) {      // stage s+1 goes into the other buffer (last read before the previous barrier)
+    if (si + 1 < ns) {      // stage si+1 goes into the other buffer (last read before the previous barrier)
       const bool f1 = kof(si + 1) + GK <= kend;
-      stage_store(ra, As2[cur ^ 1], oa, f1, tid);
-      stage_store(rb, Bs2[cur ^ 1], ob, f1, tid);
-      if (si + 2 < ns) {  // and stage s+2 starts its way from HBM / L2
-        const int k2 = kof(si + 2);
+      stage_store<GBT>(ra[SET], As2[cur ^ 1], oa, f1, tid);
+      stage_store<GBT>(rb[SET], Bs2[cur ^ 1], ob, f1, tid);
+      if (si + 1 + NS < ns) {  // and stage si+1+NS starts its way from HBM / L2
+        const int k2 = kof(si + 1 + NS);
         const bool f2 = k2 + GK <= kend;
-        load_a(ra, oa, si + 2, k2, f2);
-        stage_load(rb, ob, k2, kend, f2, tid);
+        load_a(ra[SET], oa, si + 1 + NS, k2, f2);
+        stage_load<GBT>(rb[SET], ob, k2, kend, f2, tid);
       }
     }
     // the last stage of a k range that is no multiple of GK holds zeros from kend on: its k steps of four that are all
@@ -281,23 +309,34 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
 #pragma unroll
     for (int kk = 0; kk < GK; kk += 4) {
       if (kk >= klim) break;
-      double fa[4], fb[4];
+      double fa[MI], fb[MI];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi) fa[mi] = As[(kk + fk) * GLD + wr + mi * 16 + fr];
+      for (int mi = 0; mi < MI; ++mi) fa[mi] = As[(kk + fk) * GLD + wr + mi * 16 + fr];
 #pragma unroll
-      for (int ni = 0; ni < 4; ++ni) fb[ni] = Bs[(kk + fk) * GLD + wc + ni * 16 + fr];
+      for (int ni = 0; ni < MI; ++ni) fb[ni] = Bs[(kk + fk) * GLD + wc + ni * 16 + fr];
 #pragma unroll
-      for (int mi = 0; mi < 4; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-        for (int ni = 0; ni < 4; ++ni)
+        for (int ni = 0; ni < MI; ++ni)
           acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
     }
     __syncthreads();
+    cur ^= 1;
+  };
+  if constexpr (NS == 1) {
+    for (int si = 0; si < ns; ++si) step(std::integral_constant<int, 0>{}, si);
+  } else {
+    static_assert(NS == 3, "the loop below is unrolled for three register sets");
+    for (int si = 0; si < ns; si += 3) {
+      step(std::integral_constant<int, 1>{}, si);
+      if (si + 1 < ns) step(std::integral_constant<int, 2>{}, si + 1);
+      if (si + 2 < ns) step(std::integral_constant<int, 0>{}, si + 2);
+    }
   }
 
   // epilogue: D(row = (lane>>4) + 4*reg, col = lane&15) of each 16x16 tile
   const bool partial = gridDim.z > 1;
-  if (partial && g.tickets) {
+  if constexpr (GBT == 128) if (partial && g.tickets) {
     // ---- split-K finished inside the kernel
     __shared__ int last_piece;
     const int tile_id = tm * ntn + tn;
@@ -355,9 +394,9 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   }
   const bool to_planes = partial && !g.tickets;
 #pragma unroll
-  for (int mi = 0; mi < 4; ++mi) {
+  for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-    for (int ni = 0; ni < 4; ++ni) {
+    for (int ni = 0; ni < MI; ++ni) {
       const int j = col0 + wc + ni * 16 + fr;
 #pragma unroll
       for (int reg = 0; reg < 4; ++reg) {
@@ -414,13 +453,16 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
   g.alpha = alpha; g.beta = beta; g.gamma = gamma;
   g.E2 = (gamma == 0.0) ? nullptr : E2;
   if (beta == 0.0) g.E = nullptr;
-  const int ntiles = ceil_div(g.M, GB) * ceil_div(g.N, GB);
+  // tile size: 64 where tiles of 128 would leave most of the 256 CUs without one (the solver's s x b and b x b products)
+  int gbt = GB;
+  if (ceil_div(g.M, GB) * ceil_div(g.N, GB) < tuning("gemm_tile64_below", 200) && !g.tickets) gbt = 64;
+  const int ntiles = ceil_div(g.M, gbt) * ceil_div(g.N, gbt);
   if (ntiles > GEMM_MAX_TICKETS) g.tickets = nullptr;
   // one partial plane: M x N doubles for the reduction kernel, whole 128 x 128 tiles for the in-kernel reduction
   const size_t per = g.tickets ? (size_t)ntiles * PLANE : (size_t)g.M * g.N;
   int nsplit = 1;
   if (work && ntiles < 256 && Kd >= 8 * GK) {
-    nsplit = 512 / ntiles;
+    nsplit = (gbt == 64 ? tuning("gemm_tile64_blocks", 512) : 512) / ntiles;
     // at least gemm_min_stages (default 5) stages per block: with fewer, the partial planes (and the reduction that
     // reads them back) cost more than the extra blocks gain -- the 256 x 256 x 5000 Gram products of the
     // eigensolver spent 33 us in the reduction of 128 planes next to 26 us in the GEMM
@@ -443,7 +485,8 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
     ProfScope ps("gemm_f64_kernel", st, fl);
     // second record per shape class (large / medium / small) for the bench breakdown
     ProfScope ps2(fl > 5e9 ? "gemm_large" : (fl > 2e8 ? "gemm_medium" : "gemm_small"), st, fl);
-    hipLaunchKernelGGL(gemm_f64_kernel, dim3(ntiles, 1, nsplit), dim3(256), 0, st, g);
+    if (gbt == 64) hipLaunchKernelGGL(gemm_f64_kernel<64>, dim3(ntiles, 1, nsplit), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(gemm_f64_kernel<128>, dim3(ntiles, 1, nsplit), dim3(256), 0, st, g);
   }
   FLGP_TRY(check_launch("gemm_f64_kernel"));
   if (!g.tickets && nsplit > 1) {
