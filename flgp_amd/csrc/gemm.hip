@@ -206,6 +206,61 @@ __device__ __forceinline__ void stage_store(const double (&reg)[GBT / 16], doubl
   }
 }
 
+// The fast mappings again, for a pipeline that keeps several stages in flight: every load is issued unconditionally (a
+// stage past the end of the k range reads clamped addresses) and the zeroing of the padding happens when the registers go to
+// LDS.  stage_load above chooses its mapping and its tail handling at run time; behind those branches the compiler's
+// wait-count pass cannot tell how many loads are outstanding and waits for all of them (vmcnt(0)) before every LDS store,
+// which turns a ring of register sets back into one stage of flight (measured on the 64-tile: 1.5 us per stage with one
+// set or with three).  kend must be even in the KC mapping (a thread loads two adjacent k).
+template <int GBT, int MODE>
+__device__ __forceinline__ void fast_load(double (&reg)[GBT / 16], const Operand &o, int k0, int kend, int tid) {
+  constexpr int NP = GBT / 32, KS = 512 / GBT;
+  if constexpr (MODE == LOAD_RC) {
+    const int kt = tid / (GBT / 2);
+#pragma unroll
+    for (int rep = 0; rep < NP; ++rep) {
+      const int k = k0 + kt + KS * rep;
+      const int kc = (k < kend) ? k : kend - 1;
+      const d2 v = *(const d2 *)(o.fast + (size_t)(kc - kt) * o.ks);   // o.fast sits at k = kt
+      reg[2 * rep] = v[0];
+      reg[2 * rep + 1] = v[1];
+    }
+  } else {
+    const int kl = 2 * (tid & 7);
+    const int k = k0 + kl;
+    const int kc = (k < kend) ? k : kend - 2;
+    const double *p = o.fast + (kc - kl);                               // o.fast sits at k = kl
+#pragma unroll
+    for (int rep = 0; rep < NP; ++rep) {
+      const d2 v = *(const d2 *)(p + (size_t)(32 * rep) * o.rs);
+      reg[2 * rep] = v[0];
+      reg[2 * rep + 1] = v[1];
+    }
+  }
+}
+template <int GBT, int MODE>
+__device__ __forceinline__ void fast_store(const double (&reg)[GBT / 16], double *__restrict__ lds, int k0, int kend, int tid) {
+  constexpr int NP = GBT / 32, KS = 512 / GBT, GLD = gld_of(GBT);
+  if constexpr (MODE == LOAD_RC) {
+    const int kt = tid / (GBT / 2);
+    double *q = lds + kt * GLD + 2 * (tid & (GBT / 2 - 1));
+#pragma unroll
+    for (int rep = 0; rep < NP; ++rep) {
+      const bool in = k0 + kt + KS * rep < kend;
+      q[(KS * rep) * GLD] = in ? reg[2 * rep] : 0.0;
+      q[(KS * rep) * GLD + 1] = in ? reg[2 * rep + 1] : 0.0;
+    }
+  } else {
+    const bool in = k0 + 2 * (tid & 7) < kend;
+    double *q = lds + (2 * (tid & 7)) * GLD + (tid >> 3);
+#pragma unroll
+    for (int rep = 0; rep < NP; ++rep) {
+      q[32 * rep] = in ? reg[2 * rep] : 0.0;
+      q[GLD + 32 * rep] = in ? reg[2 * rep + 1] : 0.0;
+    }
+  }
+}
+
 // The inner product runs on v_mfma_f64_16x16x4_f64.  (The 4x4x4 four-block form was tried as well: both
 // forms sustain 72-76 TFLOP/s in the bare inner loop -- scripts/ubench_inner.hip -- so the form with the
 // fewer operand reads stays.  Layout of the 4x4x4 form, probed on the device with scripts/probe_mfma4.hip:
@@ -252,7 +307,6 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   int ns = (kend - kbeg + GK - 1) / GK;
   if (ns < 0) ns = 0;
   auto kof = [&](int si) { return kbeg + si * GK; };
-  auto load_a = [&](double (&reg)[NR], const Operand &o, int si, int k0, bool full) { stage_load<GBT>(reg, o, k0, kend, full, tid); };
 
   const Operand oa = make_operand<GBT>(g.A, g.a_is, g.a_ks, row0, g.M, tid);
   const Operand ob = make_operand<GBT>(g.B, g.b_js, g.b_ks, col0, g.N, tid);
@@ -265,74 +319,102 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   // Operand stages on their way: NS register sets.  While stage si is multiplied out of one LDS buffer, set (si + 1) % NS
   // (stage si + 1, loaded NS stages ago) goes into the other buffer and is refilled with stage si + 1 + NS.  The 128-tile
   // has registers for one set (two stages of flight: its 64 MFMAs per stage cover the latency); the 64-tile does 16 MFMAs
-  // per stage and, on the shapes it is used for, runs alone on its CU: three sets, four stages of flight.
+  // per stage and, on the shapes it is used for, runs alone on its CU: three sets, four stages of flight -- with the
+  // unconditional loads of fast_load (see there), else the sets buy nothing.
   constexpr int NS = (GBT == 64) ? 3 : 1;
-  double ra[NS][NR], rb[NS][NR];
-  if (ns > 0) {
-    const int k0 = kof(0);
-    const bool f0 = k0 + GK <= kend;
-    load_a(ra[0], oa, 0, k0, f0);
-    stage_load<GBT>(rb[0], ob, k0, kend, f0, tid);
-    stage_store<GBT>(ra[0], As2[0], oa, f0, tid);
-    stage_store<GBT>(rb[0], Bs2[0], ob, f0, tid);
-#pragma unroll
-    for (int j = 1; j <= NS; ++j) {
-      if (j < ns) {
-        const int kj = kof(j);
-        const bool fj = kj + GK <= kend;
-        load_a(ra[j % NS], oa, j, kj, fj);
-        stage_load<GBT>(rb[j % NS], ob, kj, kend, fj, tid);
-      }
-    }
-  }
-  __syncthreads();
-
   const int fr = lane & 15, fk = lane >> 4;
-  int cur = 0;
-  auto step = [&](auto set_c, int si) {
-    constexpr int SET = decltype(set_c)::value;     // == (si + 1) % NS
-    const double *As = As2[cur], *Bs = Bs2[cur];
-    if (si + 1 < ns) {      // stage si+1 goes into the other buffer (last read before the previous barrier)
-      const bool f1 = kof(si + 1) + GK <= kend;
-      stage_store<GBT>(ra[SET], As2[cur ^ 1], oa, f1, tid);
-      stage_store<GBT>(rb[SET], Bs2[cur ^ 1], ob, f1, tid);
-      if (si + 1 + NS < ns) {  // and stage si+1+NS starts its way from HBM / L2
-        const int k2 = kof(si + 1 + NS);
-        const bool f2 = k2 + GK <= kend;
-        load_a(ra[SET], oa, si + 1 + NS, k2, f2);
-        stage_load<GBT>(rb[SET], ob, k2, kend, f2, tid);
+  auto pipeline = [&](auto fast_c, auto ma_c, auto mb_c) {
+    constexpr bool FAST = decltype(fast_c)::value;
+    constexpr int MA = decltype(ma_c)::value, MB = decltype(mb_c)::value;
+    double ra[NS][NR], rb[NS][NR];
+    auto load = [&](int set, int si) {          // stage si (clamped to the last one when FAST: the loads stay unconditional)
+      if constexpr (FAST) {
+        const int k0 = kof(si < ns ? si : ns - 1);
+        fast_load<GBT, MA>(ra[set], oa, k0, kend, tid);
+        fast_load<GBT, MB>(rb[set], ob, k0, kend, tid);
+      } else if (si < ns) {
+        const int k0 = kof(si);
+        const bool f = k0 + GK <= kend;
+        stage_load<GBT>(ra[set], oa, k0, kend, f, tid);
+        stage_load<GBT>(rb[set], ob, k0, kend, f, tid);
       }
-    }
-    // the last stage of a k range that is no multiple of GK holds zeros from kend on: its k steps of four that are all
-    // padding are skipped (K = 200: 2 of the 52 steps of a tile)
-    const int klim = kend - kof(si);
+    };
+    auto store = [&](int set, int si, int buf) {
+      const int k0 = kof(si);
+      if constexpr (FAST) {
+        fast_store<GBT, MA>(ra[set], As2[buf], k0, kend, tid);
+        fast_store<GBT, MB>(rb[set], Bs2[buf], k0, kend, tid);
+      } else {
+        const bool f = k0 + GK <= kend;
+        stage_store<GBT>(ra[set], As2[buf], oa, f, tid);
+        stage_store<GBT>(rb[set], Bs2[buf], ob, f, tid);
+      }
+    };
+    if (ns > 0) {
+      load(0, 0);
+      store(0, 0, 0);
 #pragma unroll
-    for (int kk = 0; kk < GK; kk += 4) {
-      if (kk >= klim) break;
-      double fa[MI], fb[MI];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) fa[mi] = As[(kk + fk) * GLD + wr + mi * 16 + fr];
-#pragma unroll
-      for (int ni = 0; ni < MI; ++ni) fb[ni] = Bs[(kk + fk) * GLD + wc + ni * 16 + fr];
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-        for (int ni = 0; ni < MI; ++ni)
-          acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+      for (int j = 1; j <= NS; ++j) load(j % NS, j);
     }
     __syncthreads();
-    cur ^= 1;
+    int cur = 0;
+    auto step = [&](auto set_c, int si) {
+      constexpr int SET = decltype(set_c)::value;     // == (si + 1) % NS
+      const double *As = As2[cur], *Bs = Bs2[cur];
+      // stage si+1 goes into the other buffer (last read before the previous barrier) and stage si+1+NS starts its way
+      // from HBM / L2.  In the FAST pipeline both happen on every step, past the end too (a repeat of the last stage into a
+      // buffer nobody reads any more): with the loads under a condition the wait-count pass gives up on counting them.
+      if (FAST || si + 1 < ns) {
+        store(SET, (FAST && si + 1 >= ns) ? ns - 1 : si + 1, cur ^ 1);
+        load(SET, si + 1 + NS);
+      }
+      // (the all-padding k steps of a ragged last stage are multiplied like the others: for K = 200 skipping them removed
+      //  4 % of the MFMAs and not a microsecond, and it puts a branch between the k steps)
+      if (si < ns) {
+#pragma unroll
+      for (int kk = 0; kk < GK; kk += 4) {
+        double fa[MI], fb[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) fa[mi] = As[(kk + fk) * GLD + wr + mi * 16 + fr];
+#pragma unroll
+        for (int ni = 0; ni < MI; ++ni) fb[ni] = Bs[(kk + fk) * GLD + wc + ni * 16 + fr];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < MI; ++ni)
+            acc[mi][ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(fa[mi], fb[ni], acc[mi][ni], 0, 0, 0);
+      }
+      }
+      __syncthreads();
+      cur ^= 1;
+    };
+    if constexpr (NS == 1) {
+      for (int si = 0; si < ns; ++si) step(std::integral_constant<int, 0>{}, si);
+    } else {
+      static_assert(NS == 3, "the loop below is unrolled for three register sets");
+      for (int si = 0; si < ns; si += 3) {
+        step(std::integral_constant<int, 1>{}, si);
+        if (FAST || si + 1 < ns) step(std::integral_constant<int, 2>{}, si + 1);
+        if (FAST || si + 2 < ns) step(std::integral_constant<int, 0>{}, si + 2);
+      }
+    }
   };
-  if constexpr (NS == 1) {
-    for (int si = 0; si < ns; ++si) step(std::integral_constant<int, 0>{}, si);
-  } else {
-    static_assert(NS == 3, "the loop below is unrolled for three register sets");
-    for (int si = 0; si < ns; si += 3) {
-      step(std::integral_constant<int, 1>{}, si);
-      if (si + 1 < ns) step(std::integral_constant<int, 2>{}, si + 1);
-      if (si + 2 < ns) step(std::integral_constant<int, 0>{}, si + 2);
+  using std::integral_constant;
+  typedef integral_constant<bool, true> yes_t;
+  typedef integral_constant<bool, false> no_t;
+  typedef integral_constant<int, LOAD_RC> rc_t;
+  typedef integral_constant<int, LOAD_KC> kc_t;
+  bool done = false;
+  if constexpr (GBT == 64) {
+    if (ns > 0 && (kend & 1) == 0 && kend - kbeg >= 2 && oa.mode != LOAD_GEN && ob.mode != LOAD_GEN) {
+      if (oa.mode == LOAD_RC && ob.mode == LOAD_RC) pipeline(yes_t{}, rc_t{}, rc_t{});
+      else if (oa.mode == LOAD_RC) pipeline(yes_t{}, rc_t{}, kc_t{});
+      else if (ob.mode == LOAD_RC) pipeline(yes_t{}, kc_t{}, rc_t{});
+      else pipeline(yes_t{}, kc_t{}, kc_t{});
+      done = true;
     }
   }
+  if (!done) pipeline(no_t{}, rc_t{}, rc_t{});
 
   // epilogue: D(row = (lane>>4) + 4*reg, col = lane&15) of each 16x16 tile
   const bool partial = gridDim.z > 1;

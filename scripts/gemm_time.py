@@ -1,0 +1,29 @@
+"""Time flgp_dev_gemm on the eigensolver's shapes as a function of the k depth (fixed cost vs per-stage cost).
+usage: python scripts/gemm_time.py [knob=value ...]"""
+import sys, torch
+sys.path.insert(0, ".")
+from flgp_amd import _lib
+L = _lib.lib()
+for kv in sys.argv[1:]:
+    k, v = kv.split("="); L.flgp_set_tuning(k.encode(), int(v))
+st = torch.cuda.current_stream().cuda_stream
+s, b = 5000, 256
+work = torch.empty(64 * 1024 * 1024 // 8 * 4, dtype=torch.float64, device="cuda")
+def run(name, M, N, Kd, A, a_s, B, b_s, C, c_s, use_work):
+    args = (st, M, N, Kd, 1.0, A.data_ptr(), a_s[0], a_s[1], B.data_ptr(), b_s[0], b_s[1], 0.0, None, 0, 0, C.data_ptr(), c_s[0], c_s[1],
+            work.data_ptr() if use_work else None, work.numel() if use_work else 0)
+    for _ in range(3): _lib.check(L.flgp_dev_gemm(*args))
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); 
+    for _ in range(50): L.flgp_dev_gemm(*args)
+    e1.record(); torch.cuda.synchronize()
+    print(f"{name:28s} M={M} N={N} K={Kd}: {e0.elapsed_time(e1) / 50 * 1e3:.1f} us")
+X = torch.randn(b, s, dtype=torch.float64, device="cuda")       # column-major s x b
+W = torch.randn(b, b, dtype=torch.float64, device="cuda")
+O = torch.empty(b, s, dtype=torch.float64, device="cuda")
+T = torch.empty(b, b, dtype=torch.float64, device="cuda")
+for Kd in (16, 64, 256):
+    run("rotate  (s x b)(b x b)", s, b, Kd, X, (1, s), W, (1, b), O, (1, s), True)
+for Kd in (16, 320, 1280, 5000):
+    run("gram    (b x s)(s x b)", b, b, Kd, X, (s, 1), X, (1, s), T, (1, b), True)
