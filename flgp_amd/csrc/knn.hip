@@ -324,7 +324,7 @@ __device__ __forceinline__ void sort_desc(float (&v)[N]) {   // bitonic network,
 // The VALU side works on packed differences: acc + 0 (PASS 0) makes the value a known-canonical float for one v_max_f32
 // per slot; acc - tau (PASS 1) turns "at or above the threshold" into a clear sign bit, so four slots are ruled out by
 // one v_max_i32 + v_max3_i32 on the bit patterns.
-template <int PASS, int CH, int QC, int PB, int DBG = 0>
+template <int PASS, int CH, int QC, int PB>
 __device__ __forceinline__ void screen_sweep(const uint4 *__restrict__ panel, const float *__restrict__ ct, int nch,
                                              uint4 (&abuf)[2][CH * 4], float (&cbuf)[2][CH], unsigned short *q,
                                              const kbf8 (&bhi)[2], const kbf8 (&blo)[2], float (&g)[2][16],
@@ -364,7 +364,7 @@ __device__ __forceinline__ void screen_sweep(const uint4 *__restrict__ panel, co
     for (int t = 0; t < 2; ++t) {
       if constexpr (PASS == 0) {
 #pragma unroll
-        for (int i = 0; i < ((DBG & 1) ? 1 : 16); ++i) g[t][i] = fmaxf(g[t][i], acc[t][i] + 0.0f);   // + 0: a float the compiler knows canonical
+        for (int i = 0; i < 16; ++i) g[t][i] = fmaxf(g[t][i], acc[t][i] + 0.0f);   // + 0: a float the compiler knows canonical
       } else {
         char *qp = (char *)(q + kh * PB + w * 64 + t * 32 + col);
 #pragma unroll
@@ -402,10 +402,10 @@ __device__ __forceinline__ void screen_sweep(const uint4 *__restrict__ panel, co
 #pragma unroll 1
     for (int tile = 0; tile < TPC; tile += 2) {
       const int j0 = c * CH + tile * 32 + 4 * kh;
-      if (!(DBG & 2)) operands(b, tile + 2 < TPC ? tile + 2 : tile, h0, l0, C0);
+      operands(b, tile + 2 < TPC ? tile + 2 : tile, h0, l0, C0);
       products(h1, l1, C1, accB);
       digest(accA, j0);
-      if (!(DBG & 2)) operands(b, tile + 3 < TPC ? tile + 3 : tile, h1, l1, C1);
+      operands(b, tile + 3 < TPC ? tile + 3 : tile, h1, l1, C1);
       products(h0, l0, C0, accA);          // past the chunk's last tile: a repeat nobody reads (no branch in the pipeline)
       digest(accB, j0 + 32);
     }
@@ -413,11 +413,13 @@ __device__ __forceinline__ void screen_sweep(const uint4 *__restrict__ panel, co
   }
 }
 
-template <int DP, int RCAP, int DBG = 0>
+template <int DP, int RCAP>
 __global__ __launch_bounds__(256, 2) void knn_screen_kernel(const double *__restrict__ X, int n, int ldx, int d,
                                                             const double *__restrict__ Ut, const double *__restrict__ uu,
                                                             int s, int r, int *__restrict__ idx_out,
                                                             double *__restrict__ dist_out, int ldo, int stop_after) {
+  // stop_after (tuning knob knn_screen_stop, 0 in production): 1 / 2 = return after pass 1 / pass 2 without results, so
+  // that scripts/knn_time.py can time the phases of this one kernel
   constexpr int NT = 256, PB = 256, CH = 256, QC = KNN_SCREEN_QC;
   static_assert(DP == 4 || DP == 8 || DP == 16, "the screen panel is written for dpad 4, 8 and 16");
   static_assert(CH == 256, "one 1 KB LDS-DMA moves a chunk's start values");
@@ -478,7 +480,7 @@ __global__ __launch_bounds__(256, 2) void knn_screen_kernel(const double *__rest
   float tau[2] = {0.0f, 0.0f};
   int cnt[2] = {0, 0};
 
-  screen_sweep<0, CH, QC, PB, DBG>(panel, ctab, nch, abuf, cbuf, q, bhi, blo, g, tau, cnt, tid);
+  screen_sweep<0, CH, QC, PB>(panel, ctab, nch, abuf, cbuf, q, bhi, blo, g, tau, cnt, tid);
   // tau: the r-th largest of the point's 32 group maxima, less the point's share of the error budget (twice: once for
   // the bounds of pass 1, once for the test of pass 2)
 #pragma unroll
@@ -883,13 +885,6 @@ template <int DP, int RCAP>
 static int launch_knn_screen(hipStream_t st, const double *dX, int n, int ldx, int d, const double *dUt,
                              const double *duu, int s, int r, int *d_idx, double *d_dist, int ldo) {
   ProfScope ps("knn_kernel", st, 2.0 * (double)n * (double)s * (double)d);
-  const int dbg = tuning("knn_screen_dbg", 0);
-  if constexpr (DP == 16 && RCAP == 16) {
-    if (dbg == 1) hipLaunchKernelGGL((knn_screen_kernel<DP, RCAP, 1>), dim3(ceil_div(n, 256)), dim3(256), 0, st, dX, n, ldx, d, dUt, duu, s, r, d_idx, d_dist, ldo, tuning("knn_screen_stop", 0));
-    if (dbg == 2) hipLaunchKernelGGL((knn_screen_kernel<DP, RCAP, 2>), dim3(ceil_div(n, 256)), dim3(256), 0, st, dX, n, ldx, d, dUt, duu, s, r, d_idx, d_dist, ldo, tuning("knn_screen_stop", 0));
-    if (dbg == 3) hipLaunchKernelGGL((knn_screen_kernel<DP, RCAP, 3>), dim3(ceil_div(n, 256)), dim3(256), 0, st, dX, n, ldx, d, dUt, duu, s, r, d_idx, d_dist, ldo, tuning("knn_screen_stop", 0));
-    if (dbg) return check_launch("knn_screen_kernel");
-  }
   hipLaunchKernelGGL((knn_screen_kernel<DP, RCAP>), dim3(ceil_div(n, 256)), dim3(256), 0, st, dX, n, ldx, d, dUt, duu, s,
                      r, d_idx, d_dist, ldo, tuning("knn_screen_stop", 0));
   return check_launch("knn_screen_kernel");
