@@ -1412,7 +1412,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     // and its wait: ~1 ms) they are spent; if n0 iterations overshoot, the degree is lowered to what the tolerance needs.
     // Without this the iteration on which the residual test is first met moves by one with perturbations of rounding
     // size (10 or 11 iterations at configs[2], depending on the start block).
-    if (it_ >= 3 && tuning("eig_landing", 1) && rmax_prev > 0.0 && rmax_prev < 1e-8 * (double)tuning("eig_landing_below_e8", 10000)) {
+    if (it_ >= 3 && tuning("eig_landing", 1) && rmax_prev > 0.0 && rmax_prev < 1e-8 * (double)tuning("eig_landing_below_e8", 100)) {
       const double gK = (theta[K - 1] - fp.c) / fp.e;
       if (gK > 1.0 + 1e-9) {
         const double a = std::acosh(gK), ln2 = 0.6931471805599453;
