@@ -474,28 +474,48 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
       }
     }
   }
+  // The 16 MI^2 results of a thread go out through one base pointer and compile-time multiples of the two strides; which
+  // terms the epilogue has (planes / E / E2) and whether the tile needs bounds checks is decided once, not per element
+  // (per element it was a chain of scalar branches and three 64-bit multiply-adds: ~20 instructions each, 3 us per tile).
   const bool to_planes = partial && !g.tickets;
+  const int ti0 = row0 + wr + fk, tj0 = col0 + wc + fr;
+  auto emit = [&](auto pl_c, auto he_c, auto he2_c, auto in_c) {
+    constexpr bool PL = decltype(pl_c)::value, HE = decltype(he_c)::value, HE2 = decltype(he2_c)::value, IN = decltype(in_c)::value;
+    const long cis = PL ? (long)g.N : g.c_is, cjs = PL ? 1L : g.c_js;
+    double *cb = (PL ? g.part + (size_t)zidx * g.M * g.N : g.C) + (size_t)ti0 * cis + (size_t)tj0 * cjs;
+    const double *eb = HE ? g.E + (size_t)ti0 * g.e_is + (size_t)tj0 * g.e_js : nullptr;
+    const double *e2b = HE2 ? g.E2 + (size_t)ti0 * g.e_is + (size_t)tj0 * g.e_js : nullptr;
 #pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
+    for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
-    for (int ni = 0; ni < MI; ++ni) {
-      const int j = col0 + wc + ni * 16 + fr;
+      for (int ni = 0; ni < MI; ++ni) {
 #pragma unroll
-      for (int reg = 0; reg < 4; ++reg) {
-        const int i = row0 + wr + mi * 16 + fk + 4 * reg;
-        if (i < g.M && j < g.N) {
+        for (int reg = 0; reg < 4; ++reg) {
+          const int di = mi * 16 + 4 * reg, dj = ni * 16;
+          if (!IN && (ti0 + di >= g.M || tj0 + dj >= g.N)) continue;
           const double v = acc[mi][ni][reg];
-          if (to_planes) {
-            g.part[((size_t)zidx * g.M + i) * g.N + j] = v;
+          if constexpr (PL) {
+            cb[(size_t)di * cis + (size_t)dj * cjs] = v;
           } else {
             double o = g.alpha * v;
-            if (g.E) o += g.beta * g.E[(size_t)i * g.e_is + (size_t)j * g.e_js];
-            if (g.E2) o += g.gamma * g.E2[(size_t)i * g.e_is + (size_t)j * g.e_js];
-            g.C[(size_t)i * g.c_is + (size_t)j * g.c_js] = o;
+            if constexpr (HE) o += g.beta * eb[(size_t)di * g.e_is + (size_t)dj * g.e_js];
+            if constexpr (HE2) o += g.gamma * e2b[(size_t)di * g.e_is + (size_t)dj * g.e_js];
+            cb[(size_t)di * cis + (size_t)dj * cjs] = o;
           }
         }
       }
     }
+  };
+  {
+    typedef std::integral_constant<bool, true> T_;
+    typedef std::integral_constant<bool, false> F_;
+    const bool inside = row0 + GB <= g.M && col0 + GB <= g.N;
+    auto pick_in = [&](auto pl_c, auto he_c, auto he2_c) { if (inside) emit(pl_c, he_c, he2_c, T_{}); else emit(pl_c, he_c, he2_c, F_{}); };
+    if (to_planes) pick_in(T_{}, F_{}, F_{});
+    else if (g.E && g.E2) pick_in(F_{}, T_{}, T_{});
+    else if (g.E) pick_in(F_{}, T_{}, F_{});
+    else if (g.E2) pick_in(F_{}, F_{}, T_{});
+    else pick_in(F_{}, F_{}, F_{});
   }
 }
 
