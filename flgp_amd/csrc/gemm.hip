@@ -564,7 +564,7 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
   const size_t per = g.tickets ? (size_t)ntiles * PLANE : (size_t)g.M * g.N;
   int nsplit = 1;
   if (work && ntiles < 256 && Kd >= 8 * GK) {
-    nsplit = (gbt == 64 ? tuning("gemm_tile64_blocks", 512) : 512) / ntiles;
+    nsplit = (gbt == 64 ? tuning("gemm_tile64_blocks", 256) : 512) / ntiles;
     // at least gemm_min_stages (default 5) stages per block: with fewer, the partial planes (and the reduction that
     // reads them back) cost more than the extra blocks gain -- the 256 x 256 x 5000 Gram products of the
     // eigensolver spent 33 us in the reduction of 128 planes next to 26 us in the GEMM
