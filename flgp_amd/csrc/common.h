@@ -77,6 +77,13 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
 constexpr int GEMM_MAX_TICKETS = 1024;
 
 
+// heat-kernel contraction on LDS-resident panels of V (hk.hip); d_vw holds hk_panel_vw_elems(n1, K) doubles
+bool hk_panel_applicable(int n0, int n1, int K);
+size_t hk_panel_vw_elems(int n1, int K);
+int hk_panel_launch(hipStream_t st, const double *d_values, int K, double t, const double *V0, long ld0, int n0,
+                    const double *dV1, int ld1, const int *d_idx1, int row0_1, int n1, double *dH, long ldh,
+                    double *d_vw);
+
 // dense algebra of the regression consumers of an EigenPair (gpr.hip)
 int chol_solve(hipStream_t st, double *dA, int N, double *dB, int nrhs, int *d_flag);
 int gpr_weights(hipStream_t st, const double *d_values, int K, double t, double *d_ls, double *d_l);

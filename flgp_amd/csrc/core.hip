@@ -31,7 +31,7 @@ int tuning(const char *key, int dflt) {
 struct ProfRec { int name_id; hipEvent_t e0, e1; double work; };
 static std::mutex g_prof_mu;
 static int g_prof_on = 0;   // 0 off, 1 only the scopes named g_prof_only, 2 every scope
-static const char *const g_prof_only = "gemm_f64_kernel";
+static const char *const g_prof_only = "hk_panel_kernel";   // the kernel bench.py's `roofline` object is about
 static std::vector<std::string> g_prof_names;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<hipEvent_t> g_prof_pool;

@@ -640,7 +640,8 @@ extern "C" int flgp_dev_gather_rows(void *stream, const double *dV, int ld, cons
 }
 
 extern "C" size_t flgp_dev_hk_workspace(int n0, int n1, int K, int gather0) {
-  return sizeof(double) * ((size_t)n1 * K + (gather0 ? (size_t)n0 * K : 0)) + 256;
+  // (the padded operand of the panel kernel, hk.hip, is the larger of the two layouts of Vw)
+  return sizeof(double) * (hk_panel_vw_elems(n1, K) + (gather0 ? (size_t)n0 * K : 0)) + 256;
 }
 
 extern "C" int flgp_dev_hk(void *stream, const double *d_values, int K, double t, const double *dV0, int ld0,
@@ -650,19 +651,22 @@ extern "C" int flgp_dev_hk(void *stream, const double *d_values, int K, double t
   FLGP_REQUIRE(K >= 1 && n0 >= 0 && n1 >= 0 && ldh >= n0, "HK: bad shape");
   if (n0 == 0 || n1 == 0) return FLGP_OK;
   double *Vw = d_work;
-  hipLaunchKernelGGL(hk_scale_kernel, dim3(ceil_div((long)n1 * K, 256)), dim3(256), 0, st, d_values, K, t, dV1, ld1,
-                     d_idx1, row0_1, n1, Vw);
-  FLGP_TRY(check_launch("hk_scale_kernel"));
   const double *V0 = dV0 + row0_0;
   long v0_ld = ld0;
   if (d_idx0) {  // general row gather (mat_indexing, src/Utils.h:130-137); callers normally pass ranges
-    double *G0 = d_work + (size_t)n1 * K;
+    double *G0 = d_work + hk_panel_vw_elems(n1, K);
     hipLaunchKernelGGL(gather_rows_kernel, dim3(ceil_div((long)n0 * K, 256)), dim3(256), 0, st, dV0, ld0, d_idx0,
                        n0, K, G0);
     FLGP_TRY(check_launch("gather_rows_kernel"));
     V0 = G0;
     v0_ld = n0;
   }
+  // the path's own shape (many rows of V against the training block): panels of V resident in LDS, hk.hip
+  if (hk_panel_applicable(n0, n1, K))
+    return hk_panel_launch(st, d_values, K, t, V0, v0_ld, n0, dV1, ld1, d_idx1, row0_1, n1, dH, ldh, Vw);
+  hipLaunchKernelGGL(hk_scale_kernel, dim3(ceil_div((long)n1 * K, 256)), dim3(256), 0, st, d_values, K, t, dV1, ld1,
+                     d_idx1, row0_1, n1, Vw);
+  FLGP_TRY(check_launch("hk_scale_kernel"));
   // H(a,b) = sum_k V0(a,k) Vw(b,k)
   return gemm_launch(st, n0, n1, K, 1.0, V0, 1, v0_ld, Vw, n1, 1, 0.0, nullptr, 0, 0, dH, 1, ldh, nullptr, 0, 0.0,
                      nullptr);

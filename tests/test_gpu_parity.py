@@ -592,6 +592,36 @@ def test_hk_gather_and_properties(oracle):
         api.HK_from_spectrum_cpp(ep, K, 1.0, np.array([n], dtype=np.int32), idx1)
 
 
+@pytest.mark.parametrize("n0,n1,K,gather", [(5000, 1000, 200, False), (2111, 77, 37, False), (4100, 300, 288, False),
+                                            (3000, 130, 100, True), (2048, 64, 16, False), (70001, 333, 210, False)])
+def test_hk_panel_kernel_bit_identical_to_gemm(oracle, n0, n1, K, gather):
+    """The LDS-panel contraction (csrc/hk.hip) against the tiled GEMM it replaces for the path's shape: the same
+    k-ascending MFMA chain per element, so every bit of H agrees -- ragged panels (n0 % 64), ragged m-tiles (n1 % 16),
+    ragged k stages (K % 16), both register variants (K <= 224 / K <= 288), row gathers, offset ranges -- and the
+    oracle's contraction within 1e-8 of max|H| (HK_from_spectrum_cpp, src/Spectrum.cpp:83-94)."""
+    rng = np.random.default_rng(n0 + n1 + K)
+    n = n0 + 50
+    vec = np.asfortranarray(rng.normal(size=(n, K)))
+    vals = np.sort(rng.uniform(0.1, 1.0, K))[::-1].copy()
+    ep = api.EigenPair(vals, vec)
+    if gather:
+        idx0 = rng.permutation(n)[:n0].astype(np.int32)
+        idx1 = rng.permutation(n)[:n1].astype(np.int32)
+    else:
+        idx0 = np.arange(7, 7 + n0, dtype=np.int32)          # an offset range: V0 starts at an odd row
+        idx1 = np.arange(3, 3 + n1, dtype=np.int32)
+    L = _lib.lib()
+    Hp = api.HK_from_spectrum_cpp(ep, K, 1.7, idx0, idx1)
+    L.flgp_set_tuning(b"hk_panel", 0)
+    try:
+        Hg = api.HK_from_spectrum_cpp(ep, K, 1.7, idx0, idx1)
+    finally:
+        L.flgp_set_tuning(b"hk_panel", 1)
+    np.testing.assert_array_equal(Hp, Hg)
+    Ho = oracle.hk_from_spectrum(vals, vec, K, 1.7, idx0, idx1)
+    assert np.abs(Hp - Ho).max() <= H_RTOL * np.abs(Ho).max()
+
+
 @pytest.mark.parametrize("path", sorted(p for p in glob.glob(os.path.join(GOLDEN, "*.npz")) if "known" not in p))
 def test_golden_fixtures_through_the_abi(path):
     g = np.load(path)
