@@ -78,8 +78,12 @@ constexpr int GEMM_MAX_TICKETS = 1024;
 
 
 // heat-kernel contraction on LDS-resident panels of V (hk.hip); d_vw holds hk_panel_vw_elems(n1, K) doubles
-bool hk_panel_applicable(int n0, int n1, int K);
+bool hk_panel_applicable(int n0, int n1, int K, long ldh);
+bool hk_panel2_applicable(int n0, int n1, int K, long ldh);    // hk2.hip: the same with the k loop unrolled (K in 97..112, 193..208)
 size_t hk_panel_vw_elems(int n1, int K);
+int hk_panel2_launch(hipStream_t st, const double *d_values, int K, double t, const double *V0, long ld0, int n0,
+                     const double *dV1, int ld1, const int *d_idx1, int row0_1, int n1, double *dH, long ldh,
+                     double *d_vw);
 int hk_panel_launch(hipStream_t st, const double *d_values, int K, double t, const double *V0, long ld0, int n0,
                     const double *dV1, int ld1, const int *d_idx1, int row0_1, int n1, double *dH, long ldh,
                     double *d_vw);

@@ -662,7 +662,9 @@ extern "C" int flgp_dev_hk(void *stream, const double *d_values, int K, double t
     v0_ld = n0;
   }
   // the path's own shape (many rows of V against the training block): panels of V resident in LDS, hk.hip
-  if (hk_panel_applicable(n0, n1, K))
+  if (hk_panel2_applicable(n0, n1, K, ldh))
+    return hk_panel2_launch(st, d_values, K, t, V0, v0_ld, n0, dV1, ld1, d_idx1, row0_1, n1, dH, ldh, Vw);
+  if (hk_panel_applicable(n0, n1, K, ldh))
     return hk_panel_launch(st, d_values, K, t, V0, v0_ld, n0, dV1, ld1, d_idx1, row0_1, n1, dH, ldh, Vw);
   hipLaunchKernelGGL(hk_scale_kernel, dim3(ceil_div((long)n1 * K, 256)), dim3(256), 0, st, d_values, K, t, dV1, ld1,
                      d_idx1, row0_1, n1, Vw);

@@ -19,6 +19,9 @@
 //   * the next panel is fetched into registers while the last m-tile of the current one is multiplied and goes to
 //     LDS between two barriers (the only two per panel: ~90 us of MFMAs apart at m = 1000).
 //
+// This is the GENERAL form (any K <= 288, run-time stage count): MFMA busy 76 %, 7 % faster than the tiled GEMM.  For
+// the stage counts of BASELINE's configurations hk2.hip unrolls the k loop and strips the issue stream (86 %).
+//
 // Arithmetic: acc = v_mfma_f64_16x16x4_f64(a, b, acc) over k ascending from acc = 0 -- the same chain per element
 // as gemm_f64_kernel (the instruction adds its four products in ascending k: scripts/probe_mfma_order.hip), so H is
 // bit for bit what the tiled GEMM gives (tests/test_gpu_parity.py::test_hk_panel_kernel_bit_identical_to_gemm).
@@ -39,11 +42,10 @@ struct HkPanelArgs {
   int K, nst;
   double *H; long ldh;                    // H(a, b) = H[a + b ldh]
   int nblocks;                            // panels: ceil(n0 / HP)
-  unsigned long long *dbg;                // diagnostic builds only (VAR == 5): s_memtime stamps per panel
 };
 
 // PG = k groups (of 4) a thread carries when a panel moves HBM -> registers -> LDS: ceil(4 nst / 8)
-template <int PG, int VAR>
+template <int PG>
 __global__ __launch_bounds__(512, 1) void hk_panel_kernel(HkPanelArgs g) {
   extern __shared__ double panel[];       // [4 nst][HP][4]
   const int tid = threadIdx.x, lane = tid & 63;
@@ -100,13 +102,9 @@ __global__ __launch_bounds__(512, 1) void hk_panel_kernel(HkPanelArgs g) {
   const unsigned h_lane = ((unsigned)fr + (unsigned)fk * (unsigned)g.ldh) * 8u;
   const double *pan_lane = panel + (size_t)fr * 4 + fk;
 
-  int dbg_i = 0;
   for (; blk < g.nblocks; blk += gridDim.x) {
-    unsigned long long ts0 = 0, ts1 = 0, ts2 = 0;
-    if constexpr (VAR == 5) ts0 = __builtin_amdgcn_s_memtime();
     panel_put();
     __syncthreads();
-    if constexpr (VAR == 5) ts1 = __builtin_amdgcn_s_memtime();
     const int nxt = blk + (int)gridDim.x;
     const bool has_next = nxt < g.nblocks;
     const int pf_at = (F > nst) ? F - nst : 0;     // the stage at which this wave sends for the next panel
@@ -148,10 +146,10 @@ __global__ __launch_bounds__(512, 1) void hk_panel_kernel(HkPanelArgs g) {
         // the reads above must be ISSUED before the four MFMAs below: the two waves of a SIMD interleave their MFMAs one
         // by one, so a wave's fourth MFMA issues ~450 cycles after its first and reads issued behind it have ~60 cycles
         // to land before the next k step wants them (left to itself the scheduler puts them there: MFMA busy 76 %)
-        if constexpr (VAR >= 1) __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) acc[ni] = __builtin_amdgcn_mfma_f64_16x16x4f64(a[kk], bf[ni], acc[ni], 0, 0, 0);
-        if constexpr (VAR >= 1) __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) bf[ni] = bn[ni];
       }
@@ -167,7 +165,7 @@ __global__ __launch_bounds__(512, 1) void hk_panel_kernel(HkPanelArgs g) {
         for (int ni = 0; ni < 4; ++ni) {
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
-            if (a0 + ni * 16 < (long)g.n0 && b0 + 4 * reg < g.n1 && (VAR != 2 || acc[ni][reg] == 1.2345e300))
+            if (a0 + ni * 16 < (long)g.n0 && b0 + 4 * reg < g.n1)
               *(double *)((char *)(hb + ni * 16 + (size_t)(4 * reg) * g.ldh) + h_lane) = acc[ni][reg];
           }
           acc[ni] = hd4{0.0, 0.0, 0.0, 0.0};
@@ -176,23 +174,15 @@ __global__ __launch_bounds__(512, 1) void hk_panel_kernel(HkPanelArgs g) {
     };
     for (int f = 0; f < F; f += 4) {
       stage(ar[0], f);
-      if constexpr (VAR != 3) a_load(ar[0]);
+      a_load(ar[0]);
       if (f + 1 < F) stage(ar[1], f + 1);
-      if constexpr (VAR != 3) a_load(ar[1]);
+      a_load(ar[1]);
       if (f + 2 < F) stage(ar[2], f + 2);
-      if constexpr (VAR != 3) a_load(ar[2]);
+      a_load(ar[2]);
       if (f + 3 < F) stage(ar[3], f + 3);
-      if constexpr (VAR != 3) a_load(ar[3]);
+      a_load(ar[3]);
     }
-    if constexpr (VAR == 5) ts2 = __builtin_amdgcn_s_memtime();
     __syncthreads();     // every wave has finished with the panel
-    if constexpr (VAR == 5) {
-      if (g.dbg && blockIdx.x < 4 && lane == 0 && dbg_i < 64) {
-        unsigned long long *d = g.dbg + (((size_t)blockIdx.x * 8 + wave) * 64 + dbg_i) * 4;
-        d[0] = ts0; d[1] = ts1; d[2] = ts2; d[3] = __builtin_amdgcn_s_memtime();
-      }
-      ++dbg_i;
-    }
   }
 }
 
@@ -212,14 +202,15 @@ __global__ void hk_scale_pad_kernel(const double *__restrict__ values, int K, in
   Vw[e] = v;
 }
 
-bool hk_panel_applicable(int n0, int n1, int K) {
+bool hk_panel_applicable(int n0, int n1, int K, long ldh) {
   const int nst = (K + 15) / 16;
   return tuning("hk_panel", 1) && nst <= HK_MAX_NST && n1 >= tuning("hk_panel_min_n1", 64) &&
-         n0 >= tuning("hk_panel_min_n0", 2048);
+         n0 >= tuning("hk_panel_min_n0", 2048) && ldh <= 150000000L;   // (a lane's store offset (3 ldh + 15) * 8 stays in 32 bits)
 }
 
+// doubles of the small operand's buffer: the larger of the two layouts (hk.hip: rows padded to 16; hk2.hip: to tile pairs)
 size_t hk_panel_vw_elems(int n1, int K) {
-  const size_t n1p = (size_t)(n1 + 15) / 16 * 16, Kp = (size_t)(K + 15) / 16 * 16;
+  const size_t n1p = (size_t)(n1 + 31) / 32 * 32, Kp = (size_t)(K + 15) / 16 * 16;
   return n1p * Kp;
 }
 
@@ -237,7 +228,6 @@ int hk_panel_launch(hipStream_t st, const double *d_values, int K, double t, con
   g.K = K; g.nst = nst;
   g.H = dH; g.ldh = ldh;
   g.nblocks = ceil_div(n0, HP);
-  g.dbg = (unsigned long long *)(((unsigned long long)(unsigned)tuning("hk_dbg_hi", 0) << 32) | (unsigned long long)(unsigned)tuning("hk_dbg_lo", 0));
   static int n_cu = 0;
   if (n_cu == 0) {
     int dev = 0, v = 0;
@@ -250,20 +240,13 @@ int hk_panel_launch(hipStream_t st, const double *d_values, int K, double t, con
   const size_t lds = sizeof(double) * (size_t)nst * 16 * HP;
   const double fl = 2.0 * (double)n0 * (double)n1 * (double)K;
   ProfScope ps("hk_panel_kernel", st, fl);
-  const int var = tuning("hk_panel_var", 1);
   auto go = [&](auto kfn) -> int {
     FLGP_HIP(hipFuncSetAttribute((const void *)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds, st, g);
     return FLGP_OK;
   };
-  if (nst <= 14) {
-    if (var == 0) FLGP_TRY(go(hk_panel_kernel<7, 0>));
-    else if (var == 2) FLGP_TRY(go(hk_panel_kernel<7, 2>));
-    else if (var == 3) FLGP_TRY(go(hk_panel_kernel<7, 3>));
-    else if (var == 5) FLGP_TRY(go(hk_panel_kernel<7, 5>));
-    else FLGP_TRY(go(hk_panel_kernel<7, 1>));
-  }
-  else { if (var == 0) FLGP_TRY(go(hk_panel_kernel<9, 0>)); else FLGP_TRY(go(hk_panel_kernel<9, 1>)); }
+  if (nst <= 14) FLGP_TRY(go(hk_panel_kernel<7>));
+  else FLGP_TRY(go(hk_panel_kernel<9>));
   return check_launch("hk_panel_kernel");
 }
 

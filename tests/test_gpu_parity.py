@@ -593,12 +593,14 @@ def test_hk_gather_and_properties(oracle):
 
 
 @pytest.mark.parametrize("n0,n1,K,gather", [(5000, 1000, 200, False), (2111, 77, 37, False), (4100, 300, 288, False),
-                                            (3000, 130, 100, True), (2048, 64, 16, False), (70001, 333, 210, False)])
+                                            (3000, 130, 100, True), (2048, 64, 16, False), (70001, 333, 210, False),
+                                            (6405, 999, 197, False), (9000, 520, 100, False), (4000, 481, 110, True)])
 def test_hk_panel_kernel_bit_identical_to_gemm(oracle, n0, n1, K, gather):
-    """The LDS-panel contraction (csrc/hk.hip) against the tiled GEMM it replaces for the path's shape: the same
-    k-ascending MFMA chain per element, so every bit of H agrees -- ragged panels (n0 % 64), ragged m-tiles (n1 % 16),
-    ragged k stages (K % 16), both register variants (K <= 224 / K <= 288), row gathers, offset ranges -- and the
-    oracle's contraction within 1e-8 of max|H| (HK_from_spectrum_cpp, src/Spectrum.cpp:83-94)."""
+    """The LDS-panel contractions (csrc/hk2.hip: unrolled, 13 or 7 stages of k, n1 >= 480; csrc/hk.hip: any K <= 288)
+    against the tiled GEMM they replace for the path's shape: the same k-ascending MFMA chain per element, so every bit
+    of H agrees between all three -- ragged panels (n0 % 64), ragged m-tiles and tile pairs (n1 % 16, n1 % 32), ragged k
+    stages (K % 16), both register variants of hk.hip (K <= 224 / K <= 288), row gathers, offset ranges -- and the oracle's
+    contraction within 1e-8 of max|H| (HK_from_spectrum_cpp, src/Spectrum.cpp:83-94)."""
     rng = np.random.default_rng(n0 + n1 + K)
     n = n0 + 50
     vec = np.asfortranarray(rng.normal(size=(n, K)))
@@ -612,12 +614,16 @@ def test_hk_panel_kernel_bit_identical_to_gemm(oracle, n0, n1, K, gather):
         idx1 = np.arange(3, 3 + n1, dtype=np.int32)
     L = _lib.lib()
     Hp = api.HK_from_spectrum_cpp(ep, K, 1.7, idx0, idx1)
-    L.flgp_set_tuning(b"hk_panel", 0)
+    L.flgp_set_tuning(b"hk_panel2", 0)
     try:
-        Hg = api.HK_from_spectrum_cpp(ep, K, 1.7, idx0, idx1)
+        H1 = api.HK_from_spectrum_cpp(ep, K, 1.7, idx0, idx1)      # the general panel kernel alone
+        L.flgp_set_tuning(b"hk_panel", 0)
+        Hg = api.HK_from_spectrum_cpp(ep, K, 1.7, idx0, idx1)      # the tiled GEMM
     finally:
         L.flgp_set_tuning(b"hk_panel", 1)
+        L.flgp_set_tuning(b"hk_panel2", 1)
     np.testing.assert_array_equal(Hp, Hg)
+    np.testing.assert_array_equal(H1, Hg)
     Ho = oracle.hk_from_spectrum(vals, vec, K, 1.7, idx0, idx1)
     assert np.abs(Hp - Ho).max() <= H_RTOL * np.abs(Ho).max()
 
