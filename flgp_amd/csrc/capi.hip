@@ -20,6 +20,30 @@ extern "C" int flgp_dev_mean(void *stream, const double *d_x, long count, double
 extern "C" int flgp_dev_se_weights_den(void *stream, const int *d_knn_idx, const double *d_knn_dist, int n, int ldk,
                                        int r, double den, int *d_ell_idx, double *d_ell_val);
 
+
+// u = A v / sigma (flgp_dev_u_recover) needs sigma > 0 for every wanted pair.  K == s on a rank-deficient A, an anchor no
+// point chose, an SE bandwidth that underflows a column: the Gram route cannot deliver those left vectors (the
+// reference's BDCSVD can), and the recovery kernel writes a zero column for sigma == 0 rather than Inf / NaN.  EVERY
+// caller of flgp_dev_eig_topk that goes on to flgp_dev_u_recover asks here first (the host spectrum did, the
+// bandwidth grid and the sharded driver did not): FLGP_OK, or FLGP_ERR_INVALID / FLGP_ERR_NOCONV with the message.
+// Synchronises the stream (flgp_dev_eig_topk has done so already: the copy is K doubles).
+extern "C" int flgp_dev_spectrum_usable(void *stream, const double *d_eig, int K) {
+  hipStream_t st = (hipStream_t)stream;
+  FLGP_REQUIRE(d_eig && K >= 1, "spectrum_usable: bad arguments");
+  std::vector<double> hv((size_t)K);
+  FLGP_HIP(hipMemcpyAsync(hv.data(), d_eig, sizeof(double) * (size_t)K, hipMemcpyDeviceToHost, st));
+  FLGP_HIP(hipStreamSynchronize(st));
+  const double top = hv[0], low = hv[K - 1];
+  if (!(top > 0.0) || !std::isfinite(top)) { set_error("spectrum: the similarity matrix is zero or not finite"); return FLGP_ERR_INVALID; }
+  if (!(low > 1e-24 * top)) {
+    set_error("spectrum: singular value %d of A is zero to working precision (sigma^2 = %.3e, sigma_1^2 = %.3e): K = %d reaches "
+              "into the null space of the similarity matrix, whose left vectors the Gram route cannot recover -- choose a smaller K",
+              K, low, top, K);
+    return FLGP_ERR_NOCONV;
+  }
+  return FLGP_OK;
+}
+
 namespace {
 
 struct Stream {
@@ -215,22 +239,7 @@ int spectrum(Sim &S, hipStream_t st, int K, int root, Spectrum &P, int *info) {
   FLGP_TRY(P.V.alloc(sizeof(double) * (size_t)S.s * K));
   FLGP_TRY(flgp_dev_eig_topk(st, P.G.as<double>(), S.s, S.s, K, 0.0, P.eig.as<double>(), P.V.as<double>(), S.s,
                              P.work.p, wb, info));
-  {
-    // u = A v / sigma needs sigma > 0.  K == s on a rank-deficient A, an anchor no point chose, an SE bandwidth that
-    // underflows a column: the Gram route cannot deliver those left vectors (the reference's BDCSVD can), and dividing
-    // would fill all of H with Inf / NaN.  flgp_dev_eig_topk has synchronised the stream: look at the values.
-    std::vector<double> hv((size_t)K);
-    FLGP_TRY(d2h(hv.data(), P.eig.p, sizeof(double) * (size_t)K, st));
-    FLGP_HIP(hipStreamSynchronize(st));
-    const double top = hv[0], low = hv[K - 1];
-    if (!(top > 0.0) || !std::isfinite(top)) { set_error("spectrum: the similarity matrix is zero or not finite"); return FLGP_ERR_INVALID; }
-    if (!(low > 1e-24 * top)) {
-      set_error("spectrum: singular value %d of A is zero to working precision (sigma^2 = %.3e, sigma_1^2 = %.3e): K = %d reaches "
-                "into the null space of the similarity matrix, whose left vectors the Gram route cannot recover -- choose a smaller K",
-                K, low, top, K);
-      return FLGP_ERR_NOCONV;
-    }
-  }
+  FLGP_TRY(flgp_dev_spectrum_usable(st, P.eig.as<double>(), K));
   // u = A v / sigma, vectors = u sqrt(n), values = sigma^2 (or sigma if root)  (:153-158)
   FLGP_TRY(P.values.alloc(sizeof(double) * (size_t)K));
   FLGP_TRY(P.vectors.alloc(sizeof(double) * (size_t)S.n * K));
@@ -1081,6 +1090,7 @@ extern "C" int flgp_se_spectrum_grid(const double *X_all, int n, int d, const do
     FLGP_TRY(eig.alloc(sizeof(double) * (size_t)K));
     FLGP_TRY(V.alloc(sizeof(double) * (size_t)s * K));
     FLGP_TRY(flgp_dev_eig_topk(ws.s, G.as<double>(), s, s, K, 0.0, eig.as<double>(), V.as<double>(), s, ework.p, wb, nullptr));
+    FLGP_TRY(flgp_dev_spectrum_usable(ws.s, eig.as<double>(), K));   // (a bandwidth that underflows a column of Z ends here, with the message)
     FLGP_TRY(vals.alloc(sizeof(double) * (size_t)K));
     FLGP_TRY(vecs.alloc(sizeof(double) * (size_t)n * K));
     FLGP_TRY(uwork.alloc(flgp_dev_u_recover_workspace(s, K)));

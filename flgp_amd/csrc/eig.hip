@@ -23,6 +23,7 @@
 // accumulated in V explicitly, so V stays orthogonal to rounding even for tiny eigenvalues.
 #include "common.h"
 #include "bsg.h"
+#include "host_wait.h"
 #include <algorithm>
 #include <mutex>
 #include <cmath>
@@ -76,26 +77,31 @@ struct HostCtxLease {
   }
 };
 
-// stream_mark: remember this point of the stream; mark_wait: host waits until the stream has reached it
+// stream_mark: remember this point of the stream; mark_wait: host waits until the stream has reached it.
+// Both waits poll the event (a round trip costs a few us instead of the ~35 us of an interrupt), but only for
+// `eig_spin_us` microseconds (default 2000: the longest stretch between two questions of a healthy solve is a
+// Rayleigh-Ritz step of ~1.2 ms); after that the thread blocks in hipEventSynchronize like any other HIP caller, so
+// a kernel that never finishes costs an idle thread, not a spinning one, and a device error surfaces as FLGP_ERR_HIP.
+static hipError_t event_wait(hipEvent_t ev) {
+  const long spin_us = tuning("eig_spin_us", 2000);
+  const int rc = bounded_wait(
+      [&]() -> int { const hipError_t e = hipEventQuery(ev); return e == hipSuccess ? 0 : (e == hipErrorNotReady ? 1 : 1000 + (int)e); },
+      [&]() -> int { const hipError_t e = hipEventSynchronize(ev); return e == hipSuccess ? 0 : 1000 + (int)e; }, spin_us);
+  return rc == 0 ? hipSuccess : (hipError_t)(rc - 1000);
+}
 static hipError_t stream_mark(hipStream_t st) {
   if (!g_ctx || !g_ctx->mark_ev) return hipStreamSynchronize(st);
   return hipEventRecord(g_ctx->mark_ev, st);
 }
 static hipError_t mark_wait() {
   if (!g_ctx || !g_ctx->mark_ev) return hipSuccess;    // stream_mark synchronised instead
-  for (;;) {
-    const hipError_t e = hipEventQuery(g_ctx->mark_ev);
-    if (e != hipErrorNotReady) return e;
-  }
+  return event_wait(g_ctx->mark_ev);
 }
 hipError_t stream_wait(hipStream_t st) {
   if (!g_ctx || !g_ctx->wait_ev || tuning("eig_spin_wait", 1) == 0) return hipStreamSynchronize(st);
-  hipError_t e = hipEventRecord(g_ctx->wait_ev, st);
+  const hipError_t e = hipEventRecord(g_ctx->wait_ev, st);
   if (e != hipSuccess) return e;
-  for (;;) {
-    e = hipEventQuery(g_ctx->wait_ev);
-    if (e != hipErrorNotReady) return e;
-  }
+  return event_wait(g_ctx->wait_ev);
 }
 
 

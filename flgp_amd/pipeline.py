@@ -154,6 +154,7 @@ class HipStages:
         K, s = V.shape
         values = self.empty((K,)); vectors = self.empty((K, max(n, 1)))
         work = self.empty((self.L.flgp_dev_u_recover_workspace(s, K) // 8 + 1,))
+        _lib.check(self.L.flgp_dev_spectrum_usable(self._st(), eig.data_ptr(), K))      # sigma_K > 0, or the reason why not
         _lib.check(self.L.flgp_dev_u_recover(self._st(), ell_idx.data_ptr(), ell_val.data_ptr(), n, r, V.data_ptr(), s, s,
                                              eig.data_ptr(), K, float(scale), int(bool(root)), vectors.data_ptr(), max(n, 1),
                                              values.data_ptr(), work.data_ptr()))

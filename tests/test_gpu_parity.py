@@ -894,6 +894,27 @@ def test_se_bandwidth_grid(oracle):
     print(f"SE grid: 10 spectra concurrent {t_par*1e3:.1f} ms, sequential {t_seq*1e3:.1f} ms")
 
 
+def test_unusable_spectrum_is_refused_on_every_path(stages):
+    """sigma_K = 0 (K reaches into the null space: here K == s with an anchor that no point chose, and an SE bandwidth
+    far below the neighbour distances) has no left vectors on the Gram route.  Every path that goes from the
+    eigensolver to u = A v / sigma must say so -- the host spectrum, the bandwidth grid and the device stage the sharded
+    driver uses (the last two returned zero / noise columns with FLGP_OK)."""
+    n, d, s, r, m = 600, 3, 40, 3, 50
+    X, U0, U = make_case(n, d, s, r, seed=31)
+    U = U.copy(); U[7, :d] = 1e6                      # an anchor far away from every point: its column of Z is empty
+    U0 = np.asfortranarray(U[:, :d])
+    with pytest.raises(api.FlgpError):
+        api.heat_kernel_spectrum_cpp(X[:m], X[m:], s, r, s, dict(kernel="lae", gl="rw", root=True), U=U)
+    with pytest.raises(api.FlgpError):
+        api.se_spectrum_grid(X[:m], X[m:], s, r, K=s, a2s=np.array([1.0]), models=dict(gl="rw"), U=U, max_parallel=1)
+    # the device stage: eigenvalues with a zero at the end
+    eig = torch.tensor([1.0, 0.5, 0.0], dtype=torch.float64, device="cuda:0")
+    V = torch.eye(3, s, dtype=torch.float64, device="cuda:0")
+    ei = torch.zeros((8, r), dtype=torch.int32, device="cuda:0"); ev = torch.ones((8, r), dtype=torch.float64, device="cuda:0")
+    with pytest.raises(Exception):
+        stages.u_recover(ei, ev, V, eig, 1.0, True)
+
+
 def test_pipeline_matches_host_entry_points(oracle, stages):
     n, d, s, r, K, m, t = 3000, 16, 300, 10, 40, 128, 6.0
     X, U0, U = make_case(n, d, s, r, seed=2024)
@@ -1042,25 +1063,29 @@ def test_c5_nystrom_full_size(oracle, stages):
 
 
 # ------------------------------------------------------------------------------ row sharding on the real stages
-def _shard_worker(rank, world, port, out):
+def _shard_worker(rank, world, port, out, cfg=(6000, 16, 400, 10, 40, 300, 5.0, 5, 314), sample=None):
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)   # RCCL refuses two ranks on one card
     try:
         from flgp_amd.pipeline import shard_bounds
-        n, d, s, r, K, m, t = 6000, 16, 400, 10, 40, 300, 5.0
+        n, d, s, r, K, m, t, comps, seed = cfg
         st = HipStages("cuda:0")
         path = HeatKernelPath(st)
         lo, hi = shard_bounds(n, world, rank)
-        X = synth.gaussian_mixture(hi - lo, d, components=5, seed=314, row_offset=lo)
-        sel = np.sort(synth.random_anchor_rows(n, s, seed=314))
+        X = synth.gaussian_mixture(hi - lo, d, components=comps, seed=seed, row_offset=lo)
+        sel = np.sort(synth.random_anchor_rows(n, s, seed=seed))
         mine = sel[(sel >= lo) & (sel < hi)] - lo
         U = path.gather_anchors(torch.from_numpy(np.ascontiguousarray(X[mine].T)).cuda())
         dX = cm(X)
         sizes = path.cluster_sizes(dX, st.anchor_prep(U))
         res = path.run(dX, U, PathConfig(s=s, r=r, K=K, t=t, m=m), n, lo, num_class=sizes)
-        np.save(os.path.join(out, f"H_{world}_{rank}.npy"), to_np_cm(res.H))
+        if sample is None:
+            np.save(os.path.join(out, f"H_{world}_{rank}.npy"), to_np_cm(res.H))
+        else:      # full-size runs: the rows of `sample` (global indices) this rank owns, in order
+            loc = sample[(sample >= lo) & (sample < hi)] - lo
+            np.save(os.path.join(out, f"H_{world}_{rank}.npy"), res.H[:, torch.from_numpy(loc).cuda()].T.contiguous().cpu().numpy())
         np.save(os.path.join(out, f"v_{world}_{rank}.npy"), res.values.cpu().numpy())
     finally:
         dist.destroy_process_group()
@@ -1083,3 +1108,30 @@ def test_row_sharding_two_ranks_on_one_gpu(tmp_path):
     assert H1.shape == H2.shape == (6000, 300)
     assert np.abs(H1 - H2).max() <= H_RTOL * np.abs(H1).max()
     np.testing.assert_allclose(np.load(os.path.join(out, "v_2_1.npy")), np.load(os.path.join(out, "v_1_0.npy")), rtol=EIG_RTOL)
+
+
+def test_c4_full_size_row_sharded_two_ranks(tmp_path):
+    """BASELINE configs[3] (C4): the n = 1e6, d = 16, s = 5000, r = 10, K = 200 workload of configs[2] row-sharded over
+    two ranks (the one card of this box, gloo standing in for RCCL, the real HIP stages on every rank: k-NN, LAE,
+    Laplacian, Gram partials, replicated eigensolve, U-recovery, H) against the single-rank run: eigenvalues 1e-10, H on
+    the training block and 8192 sampled rows 1e-8 of max|H| (the column sums and the Gram matrix are added in a
+    different association across ranks, nothing else differs)."""
+    import socket
+    import torch.multiprocessing as mp
+    out = str(tmp_path)
+    cfg = (1_000_000, 16, 5000, 10, 200, 1000, 10.0, 16, 20241022)
+    rng = np.random.default_rng(4)
+    sample = np.sort(np.concatenate([np.arange(1000), 1000 + rng.choice(999_000, 8192, replace=False)]))
+    for world in (1, 2):
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        mp.spawn(_shard_worker, args=(world, port, out, cfg, sample), nprocs=world, join=True)
+    H1 = np.load(os.path.join(out, "H_1_0.npy"))
+    H2 = np.vstack([np.load(os.path.join(out, f"H_2_{r}.npy")) for r in range(2)])
+    assert H1.shape == H2.shape == (sample.size, 1000)
+    assert np.abs(H1 - H2).max() <= H_RTOL * np.abs(H1).max(), np.abs(H1 - H2).max() / np.abs(H1).max()
+    v1 = np.load(os.path.join(out, "v_1_0.npy"))
+    for r in range(2):
+        np.testing.assert_allclose(np.load(os.path.join(out, f"v_2_{r}.npy")), v1, rtol=EIG_RTOL)
+    assert abs(v1[0] - 1.0) < 1e-6

@@ -65,3 +65,15 @@ def test_constant_division_identity(tmp_path):
     out = subprocess.run([exe, "1000000"], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout
     assert "mismatches 0" in out.stdout
+
+
+def test_bounded_host_wait(tmp_path):
+    """The eigensolver's host waits poll an event for at most `eig_spin_us` and then block (csrc/host_wait.h,
+    used by csrc/eig.hip): a hung kernel must not pin a spinning thread, errors must come back.  The logic is generic
+    over the query / block operations and is exercised here on the CPU."""
+    import subprocess
+    src = os.path.join(os.path.dirname(__file__), "c", "host_wait_check.cc")
+    exe = str(tmp_path / "host_wait_check")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", src, "-o", exe], check=True)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "host_wait ok" in out.stdout, out.stdout
