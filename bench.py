@@ -53,6 +53,9 @@ def parse():
     ap.add_argument("--tune", action="append", default=[], help="key=value tuning knobs (experiments)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events (no roofline object)")
     ap.add_argument("--no-e2e", action="store_true", help="skip the host-boundary (PCIe-inclusive) timing of the C entry point")
+    ap.add_argument("--driver", choices=["auto", "c", "python"], default="auto",
+                    help="who drives the sharded path: the C entry point flgp_dev_heat_kernel_covariance_sharded with an RCCL "
+                         "flgp_comm (default for N > 1), or flgp_amd/pipeline.py over torch.distributed (default for N = 1: it times the stages)")
     return ap.parse_args()
 
 
@@ -139,6 +142,40 @@ def main():
         k, v = kv.split("=")
         L.flgp_set_tuning(k.encode(), int(v))
 
+    # ---- N > 1: the exchanges go through the C ABI's communicator table (RCCL, one rank per process; the 128-byte id
+    #      travels over the process group that the launcher has set up).  Any failure falls back to the Python driver.
+    comm = None
+    driver_note = None
+    want_c = args.driver == "c" or (args.driver == "auto" and world > 1 and backend == "nccl")
+    if want_c and world > 1:
+        try:
+            import torch.distributed as dist
+            idbuf = (ctypes.c_char * 128)()
+            if rank == 0:
+                _lib.check(L.flgp_comm_rccl_unique_id(idbuf))
+            idt = torch.frombuffer(bytearray(bytes(idbuf)), dtype=torch.uint8).to(device)
+            dist.broadcast(idt, src=0)
+            raw = bytes(idt.cpu().numpy().tobytes())
+            cbuf = (ctypes.c_char * 128).from_buffer_copy(raw)
+            out_c = (ctypes.c_void_p * 1)()
+            _lib.check(L.flgp_comm_rccl_init_rank(world, rank, cbuf, out_c))
+            comm = out_c[0]
+            probe = torch.ones(4, dtype=torch.float64, device=device)
+            _lib.check(L.flgp_comm_all_reduce_sum(comm, probe.data_ptr(), 4, torch.cuda.current_stream(device).cuda_stream))
+            torch.cuda.synchronize(device)
+            if float(probe[0].item()) != float(world):
+                raise RuntimeError("the C communicator's all-reduce of ones gave %r, expected %d" % (float(probe[0].item()), world))
+        except Exception as e:      # noqa: BLE001
+            driver_note = "C driver unavailable (%r): Python driver over torch.distributed instead" % (e,)
+            comm = None
+        # every rank must take the same road
+        ok = torch.tensor([1 if comm is not None else 0], dtype=torch.int64, device=device)
+        torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+        if int(ok.item()) == 0 and comm is not None:
+            L.flgp_comm_destroy(comm); comm = None
+            driver_note = "C driver unavailable on another rank: Python driver over torch.distributed instead"
+    use_c = comm is not None or (args.driver == "c" and world == 1)
+
     n, d, s = args.n, args.d, args.s
     lo, hi = shard_bounds(n, world, rank)
     n_loc = hi - lo
@@ -149,19 +186,41 @@ def main():
     sel = np.sort(synth.random_anchor_rows(n, s))
     mine = sel[(sel >= lo) & (sel < hi)] - lo
     U_local = torch.from_numpy(np.ascontiguousarray(X_np[mine, :].T)).to(device)
-    U = path.gather_anchors(U_local)
-    assert U.shape == (d, s)
-    anchors = stages.anchor_prep(U)
-    num_class = path.cluster_sizes(X_loc, anchors)                           # 1-NN counts over all ranks
     cfg = PathConfig(s=s, r=args.r, K=args.K, t=args.t, m=args.m)
+    if use_c:
+        st_ = lambda: torch.cuda.current_stream(device).cuda_stream     # noqa: E731
+        U = torch.empty((d, s), dtype=torch.float64, device=device)
+        _lib.check(L.flgp_dev_gather_anchors(st_(), comm, U_local.data_ptr(), U_local.shape[1], d, U.data_ptr(), s))
+        num_class = torch.empty(s, dtype=torch.float64, device=device)
+        _lib.check(L.flgp_dev_cluster_sizes(st_(), comm, X_loc.data_ptr(), n_loc, n_loc, d, U.data_ptr(), s, s, num_class.data_ptr()))
+    else:
+        U = path.gather_anchors(U_local)
+        anchors = stages.anchor_prep(U)
+        num_class = path.cluster_sizes(X_loc, anchors)                           # 1-NN counts over all ranks
+    assert U.shape == (d, s)
 
     def barrier():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(device)
 
+    class _CRes:
+        stage_ms = {}
+        eig_info = {}
+
     def step():
-        return path.run(X_loc, U, cfg, n, lo, num_class=num_class)
+        if not use_c:
+            return path.run(X_loc, U, cfg, n, lo, num_class=num_class)
+        res = _CRes()
+        res.H = torch.empty((args.m, n_loc), dtype=torch.float64, device=device)
+        info = (ctypes.c_int * 4)()
+        _lib.check(L.flgp_dev_heat_kernel_covariance_sharded(
+            torch.cuda.current_stream(device).cuda_stream, comm, X_loc.data_ptr(), n_loc, n_loc, d, n, lo, U.data_ptr(), s, s,
+            num_class.data_ptr(), args.m, args.r, args.t, args.K, b"lae", b"cluster-normalized", 1, 0.1, res.H.data_ptr(), n_loc,
+            None, None, 0, ctypes.addressof(info)))
+        res.eig_info = dict(outer_iterations=info[0], g_products=info[1], dense=bool(info[2]),
+                            newton_schulz_orths=info[3] // 1000, jacobi_orths=info[3] % 1000)
+        return res
 
     res = None
     for _ in range(args.warmup):
@@ -228,7 +287,9 @@ def main():
         "config": {"workload": f"Gaussian-mixture n={n} d={d} s={s} r={args.r} K={args.K} m={args.m} t={args.t} "
                                f"kernel=lae gl=cluster-normalized root=TRUE (BASELINE configs[{2 if world == 1 else 3}])",
                    "parallelism": f"row-sharded x{world}", "rows_per_gpu": n_loc, "ranks_seen": ranks_seen,
-                   "eig": res.eig_info},
+                   "driver": ("C ABI: flgp_dev_heat_kernel_covariance_sharded, exchanges through flgp_comm (RCCL)" if use_c else
+                              "flgp_amd/pipeline.py (stage by stage through the C ABI" + (", exchanges over torch.distributed)" if world > 1 else ")")),
+                   "driver_note": driver_note, "eig": res.eig_info},
         "stage_ms_per_step": {k: v / args.steps for k, v in stage_acc.items()},
         "kernels_diagnostic_step": kernels,
     }
@@ -266,6 +327,8 @@ def main():
         if args.verbose:
             print(json.dumps(out, indent=1), file=sys.stderr)
         print(json.dumps(out))
+    if comm is not None:
+        L.flgp_comm_destroy(comm)
     if world > 1:
         torch.distributed.destroy_process_group()
 

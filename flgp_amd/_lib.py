@@ -22,6 +22,7 @@ _SIGNATURES = {
     "flgp_last_error": (c_char_p, []),
     "flgp_version": (c_char_p, []),
     "flgp_device_count": (c_int, []),
+    "flgp_dev_pool_release": (c_size_t, []),
     "flgp_set_device": (c_int, [c_int]),
     "flgp_parse_gl": (c_int, [c_char_p]),
     "flgp_set_tuning": (c_int, [c_char_p, c_int]),
@@ -94,6 +95,23 @@ _SIGNATURES = {
     "flgp_dev_gemm": (c_int, [P, c_int, c_int, c_int, c_double, P, c_long, c_long, P, c_long, c_long,
                               c_double, P, c_long, c_long, P, c_long, c_long, P, c_size_t]),
     "flgp_dev_gather_rows": (c_int, [P, P, c_int, P, c_int, c_int, P]),
+    # row-sharded path behind the C ABI: communicators + sharded entry points
+    "flgp_comm_inproc_create": (c_int, [c_int, P]),
+    "flgp_comm_rccl_unique_id": (c_int, [P]),
+    "flgp_comm_rccl_init_rank": (c_int, [c_int, c_int, P, P]),
+    "flgp_comm_rccl_init_all": (c_int, [c_int, P, P]),
+    "flgp_comm_destroy": (None, [P]),
+    "flgp_comm_all_reduce_sum": (c_int, [P, P, c_size_t, P]),
+    "flgp_comm_all_gather": (c_int, [P, P, P, c_size_t, P]),
+    "flgp_comm_rank": (c_int, [P]),
+    "flgp_comm_world": (c_int, [P]),
+    "flgp_dev_gather_anchors": (c_int, [P, P, P, c_int, c_int, P, c_int]),
+    "flgp_dev_cluster_sizes": (c_int, [P, P, P, c_int, c_int, c_int, P, c_int, c_int, P]),
+    "flgp_dev_heat_kernel_covariance_sharded": (c_int, [P, P, P, c_int, c_int, c_int, c_long, c_long, P, c_int, c_int, P, c_int,
+                                                        c_int, c_double, c_int, c_char_p, c_char_p, c_int, c_double, P, c_int,
+                                                        P, P, c_int, P]),
+    "flgp_heat_kernel_covariance_multi": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, c_double, c_int, c_char_p,
+                                                  c_char_p, c_int, c_double, c_int, P, P]),
     "flgp_dev_hk_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
 }
 

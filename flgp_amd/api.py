@@ -352,8 +352,19 @@ def heat_kernel_spectrum_cpp(X, X_new, s, r, K=-1, models=None, nstart=1, epsilo
     return EigenPair(values, vectors)
 
 
-def heat_kernel_covariance_cpp(X, X_new, s, r, t, K, models, nstart, epsilon, U=None):
-    """heat_kernel_covariance_cpp (src/Spectrum.cpp:28-43): H is (m + m_new) x m."""
+def _devices_from_env():
+    """FLGP_DEVICES="0,1,2,3": the GPUs the row-sharded entry point uses (the R shim reads the same variable)."""
+    import os
+    v = os.environ.get("FLGP_DEVICES", "").strip()
+    return [int(x) for x in v.split(",") if x.strip() != ""] if v else None
+
+
+def heat_kernel_covariance_cpp(X, X_new, s, r, t, K, models, nstart, epsilon, U=None, devices=None):
+    """heat_kernel_covariance_cpp (src/Spectrum.cpp:28-43): H is (m + m_new) x m.
+
+    ``devices`` (or the environment variable FLGP_DEVICES) lists the GPUs to shard the rows over: the call then goes
+    to ``flgp_heat_kernel_covariance_multi`` (one host thread per listed device, RCCL or the in-process transport;
+    include/flgp_hip.h, "Row-sharded path").  Not an argument of the reference, which is single-process."""
     models = dict(_DEFAULT_MODELS_CPP, **(models or {}))
     X = _f64(X, "X"); X_new = _f64(X_new, "X_new")
     m = X.shape[0]
@@ -361,17 +372,25 @@ def heat_kernel_covariance_cpp(X, X_new, s, r, t, K, models, nstart, epsilon, U=
     n, d = X_all.shape
     U = _anchors(X_all, s, models, U, nstart)
     H = np.zeros((n, m), order="F")
+    if devices is None:
+        devices = _devices_from_env()
+    if devices is not None and len(devices) > 1:
+        dev = np.ascontiguousarray(devices, dtype=np.int32)
+        check(_lib.lib().flgp_heat_kernel_covariance_multi(_ptr(X_all), n, m, d, _ptr(U), s, U.shape[1], int(r), float(t), int(K),
+                                                           _b(models["kernel"]), _b(models["gl"]), int(bool(models["root"])),
+                                                           float(epsilon), dev.size, _ptr(dev), _ptr(H)))
+        return H
     check(_lib.lib().flgp_heat_kernel_covariance(_ptr(X_all), n, m, d, _ptr(U), s, U.shape[1], int(r), float(t), int(K),
                                                  _b(models["kernel"]), _b(models["gl"]), int(bool(models["root"])),
                                                  float(epsilon), _ptr(H)))
     return H
 
 
-def heat_kernel_covariance_rcpp(X, X_new, s, r, t, K=-1, models=None, epsilon=0.1, nstart=1, U=None):
+def heat_kernel_covariance_rcpp(X, X_new, s, r, t, K=-1, models=None, epsilon=0.1, nstart=1, U=None, devices=None):
     """heat_kernel_covariance_rcpp (R/Fit.R:760-770), with the R wrapper's defaults
     (gl="cluster-normalized", root=TRUE, K=-1)."""
     models = dict(_DEFAULT_MODELS_R, **(models or {}))
-    return heat_kernel_covariance_cpp(X, X_new, s, r, t, K, models, nstart, epsilon, U=U)
+    return heat_kernel_covariance_cpp(X, X_new, s, r, t, K, models, nstart, epsilon, U=U, devices=devices)
 
 
 def se_spectrum_grid(X, X_new, s, r, K=-1, a2s=None, models=None, nstart=1, U=None, max_parallel=10):

@@ -118,6 +118,13 @@ struct Sim {
   DevBuf X, U, Ut, uu, knn_idx, knn_dist, ell_idx, ell_val, colptr, pos, colsum, cswork, work, num_class;
   int n = 0, d = 0, s = 0, r = 0;
   bool have_csc = false;
+  // row-sharded runs (flgp_dev_heat_kernel_covariance_sharded): n is the LOCAL row count, ldx the leading dimension of
+  // the caller's X block, comm carries the exchanges of SURVEY 8e, n_global scales the eigenvectors, sizes overrides U's
+  // last column as the cluster sizes
+  int ldx = 0;
+  const flgp_comm *comm = nullptr;
+  long n_global = 0;
+  const double *sizes = nullptr;
 };
 
 int upload_points(Sim &S, hipStream_t st, const double *X, int n, int d, const double *U, int s, int ucols,
@@ -152,7 +159,7 @@ int run_knn(Sim &S, hipStream_t st, int r, bool want_dist) {
   S.r = r;
   FLGP_TRY(S.knn_idx.alloc(sizeof(int) * (size_t)S.n * r));
   if (want_dist) FLGP_TRY(S.knn_dist.alloc(sizeof(double) * (size_t)S.n * r));
-  return flgp_dev_knn(st, S.X.as<double>(), S.n, S.n, S.d, S.Ut.as<double>(), S.uu.as<double>(), S.s, r,
+  return flgp_dev_knn(st, S.X.as<double>(), S.n, S.ldx ? S.ldx : S.n, S.d, S.Ut.as<double>(), S.uu.as<double>(), S.s, r,
                       S.knn_idx.as<int>(), want_dist ? S.knn_dist.as<double>() : nullptr, S.n);
 }
 
@@ -184,6 +191,7 @@ int build_csc(Sim &S, hipStream_t st) {
 int laplacian(Sim &S, hipStream_t st, int gl, const double *d_num_class) {
   if (gl != FLGP_GL_RW) {
     FLGP_TRY(colsum_of(S, st, S.ell_idx.as<int>(), S.ell_val.as<double>()));
+    FLGP_TRY(flgp_comm_all_reduce_sum(S.comm, S.colsum.as<double>(), (size_t)S.s, st));            // exchange 2a
     FLGP_TRY(flgp_dev_col_scale(st, S.ell_idx.as<int>(), S.ell_val.as<double>(), S.n, S.r, S.colsum.as<double>(),
                                 gl == FLGP_GL_CLUSTER_NORMALIZED ? d_num_class : nullptr, 0));
   }
@@ -198,10 +206,10 @@ int cross_similarity(Sim &S, hipStream_t st, int r, int kernel_se, int gl, doubl
     FLGP_TRY(flgp_dev_se_weights(st, S.knn_idx.as<int>(), S.knn_dist.as<double>(), S.n, S.n, r, epsilon,
                                  S.ell_idx.as<int>(), S.ell_val.as<double>()));
   else
-    FLGP_TRY(flgp_dev_lae(st, S.X.as<double>(), S.n, S.n, S.d, S.Ut.as<double>(), S.s, r, S.knn_idx.as<int>(), S.n,
+    FLGP_TRY(flgp_dev_lae(st, S.X.as<double>(), S.n, S.ldx ? S.ldx : S.n, S.d, S.Ut.as<double>(), S.s, r, S.knn_idx.as<int>(), S.n,
                           S.ell_idx.as<int>(), S.ell_val.as<double>()));
   if (gl < 0) return FLGP_OK;  // LAE_cpp alone: no graph-Laplacian normalisation
-  const double *sizes = (ucols == S.d + 1) ? S.U.as<double>() + (size_t)S.d * S.s : nullptr;  // U.col(d)
+  const double *sizes = S.sizes ? S.sizes : ((ucols == S.d + 1) ? S.U.as<double>() + (size_t)S.d * S.s : nullptr);  // U.col(d)
   return laplacian(S, st, gl, sizes);
 }
 
@@ -228,11 +236,24 @@ int spectrum(Sim &S, hipStream_t st, int K, int root, Spectrum &P, int *info) {
   FLGP_TRY(build_csc(S, st));
   // A = Z diag(1/sqrt(|colsum|+1e-9))  (:149-150)
   FLGP_TRY(colsum_of(S, st, S.ell_idx.as<int>(), S.ell_val.as<double>()));
+  FLGP_TRY(flgp_comm_all_reduce_sum(S.comm, S.colsum.as<double>(), (size_t)S.s, st));              // exchange 2b
   FLGP_TRY(flgp_dev_col_scale(st, S.ell_idx.as<int>(), S.ell_val.as<double>(), S.n, S.r, S.colsum.as<double>(), nullptr, 1));
   // Gram + top-K eigenpairs (replaces RSpectra::svds / BDCSVD, src/TruncatedSVD.cpp:17-30)
   FLGP_TRY(P.G.alloc(sizeof(double) * (size_t)S.s * S.s));
   FLGP_TRY(flgp_dev_gram(st, S.ell_idx.as<int>(), S.ell_val.as<double>(), S.n, S.s, S.r, S.colptr.as<int>(),
                          S.pos.as<int>(), P.G.as<double>(), S.s));
+  if (flgp_comm_world(S.comm) > 1) {
+    // exchange 3: the Gram partials of the row blocks.  Only the upper triangle travels (s(s+1)/2 doubles); unpacking
+    // mirrors it, which also leaves G symmetric bit for bit whatever order the transport added the ranks in.  The
+    // eigensolve below then runs replicated: every rank holds the same G.
+    DevBuf packed;
+    const size_t cnt = (size_t)S.s * ((size_t)S.s + 1) / 2;
+    FLGP_TRY(packed.alloc(sizeof(double) * cnt));
+    FLGP_TRY(flgp_dev_sym_pack(st, P.G.as<double>(), S.s, S.s, packed.as<double>()));
+    FLGP_TRY(flgp_comm_all_reduce_sum(S.comm, packed.as<double>(), cnt, st));
+    FLGP_TRY(flgp_dev_sym_unpack(st, packed.as<double>(), S.s, P.G.as<double>(), S.s));
+    FLGP_HIP(hipStreamSynchronize(st));     // (packed dies here)
+  }
   const size_t wb = flgp_dev_eig_workspace(S.s, K);
   FLGP_TRY(P.work.alloc(wb));
   FLGP_TRY(P.eig.alloc(sizeof(double) * (size_t)K));
@@ -245,8 +266,8 @@ int spectrum(Sim &S, hipStream_t st, int K, int root, Spectrum &P, int *info) {
   FLGP_TRY(P.vectors.alloc(sizeof(double) * (size_t)S.n * K));
   FLGP_TRY(P.uwork.alloc(flgp_dev_u_recover_workspace(S.s, K)));
   return flgp_dev_u_recover(st, S.ell_idx.as<int>(), S.ell_val.as<double>(), S.n, S.r, P.V.as<double>(), S.s, S.s,
-                            P.eig.as<double>(), K, std::sqrt((double)S.n), root, P.vectors.as<double>(), S.n,
-                            P.values.as<double>(), P.uwork.as<double>());
+                            P.eig.as<double>(), K, std::sqrt((double)(S.n_global ? S.n_global : (long)S.n)), root,
+                            P.vectors.as<double>(), S.n, P.values.as<double>(), P.uwork.as<double>());
 }
 
 int parse_kernel(const char *kernel, int *se) {
@@ -1007,6 +1028,237 @@ extern "C" int flgp_heat_kernel_covariance(const double *X_all, int n, int m, in
   if (verbose)
     fprintf(stderr, "[flgp e2e] upload %.1f ms, similarity + spectrum %.1f ms, H to host %.1f ms\n", (t1 - t0) * 1e3, (t2 - t1) * 1e3,
             (now() - t2) * 1e3);
+  return FLGP_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Row-sharded path behind the C ABI (include/flgp_hip.h, "Row-sharded path"): the driver that
+// flgp_amd/pipeline.py is in Python, with the exchanges going through an flgp_comm table instead of torch.distributed.
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ void count_labels_kernel(const int *__restrict__ lab, long n, int s, int *__restrict__ cnt) {
+  const long stride = (long)gridDim.x * blockDim.x;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+    const int q = lab[i];
+    if (q >= 0 && q < s) atomicAdd(&cnt[q], 1);      // integer counts: exact whatever the order
+  }
+}
+__global__ void int_to_double_kernel(const int *__restrict__ in, int n, double *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (double)in[i];
+}
+}  // namespace
+
+extern "C" int flgp_dev_gather_anchors(void *stream, const flgp_comm *comm, const double *dU_loc, int s_loc, int d,
+                                       double *dU_out, int s_total) {
+  hipStream_t st = (hipStream_t)stream;
+  FLGP_REQUIRE(dU_out && s_loc >= 0 && d >= 1 && s_total >= s_loc && (dU_loc || s_loc == 0), "gather_anchors: bad arguments");
+  const int world = flgp_comm_world(comm), rank = flgp_comm_rank(comm);
+  if (world == 1) {
+    FLGP_REQUIRE(s_total == s_loc, "gather_anchors: one rank, but s_total != s_loc");
+    if (dU_out != dU_loc && s_loc) FLGP_HIP(hipMemcpyAsync(dU_out, dU_loc, sizeof(double) * (size_t)s_loc * d, hipMemcpyDeviceToDevice, st));
+    return FLGP_OK;
+  }
+  // the counts first (as doubles through the same collective), then the blocks padded to the largest count
+  DevBuf cnt_s, cnt_r;
+  FLGP_TRY(cnt_s.alloc(sizeof(double)));
+  FLGP_TRY(cnt_r.alloc(sizeof(double) * (size_t)world));
+  const double mine = (double)s_loc;
+  FLGP_HIP(hipMemcpyAsync(cnt_s.p, &mine, sizeof(double), hipMemcpyHostToDevice, st));
+  FLGP_TRY(flgp_comm_all_gather(comm, cnt_s.as<double>(), cnt_r.as<double>(), 1, st));
+  std::vector<double> hc((size_t)world);
+  FLGP_HIP(hipMemcpyAsync(hc.data(), cnt_r.p, sizeof(double) * (size_t)world, hipMemcpyDeviceToHost, st));
+  FLGP_HIP(hipStreamSynchronize(st));
+  int smax = 0; long sum = 0;
+  for (int q = 0; q < world; ++q) { smax = std::max(smax, (int)hc[q]); sum += (long)hc[q]; }
+  FLGP_REQUIRE(sum == s_total && (int)hc[rank] == s_loc, "gather_anchors: the ranks contribute %ld anchors, s_total = %d", sum, s_total);
+  if (smax == 0) return FLGP_OK;
+  DevBuf pad, all;
+  FLGP_TRY(pad.alloc(sizeof(double) * (size_t)smax * d));
+  FLGP_TRY(all.alloc(sizeof(double) * (size_t)smax * d * world));
+  FLGP_HIP(hipMemsetAsync(pad.p, 0, sizeof(double) * (size_t)smax * d, st));
+  if (s_loc)
+    FLGP_HIP(hipMemcpy2DAsync(pad.p, sizeof(double) * (size_t)smax, dU_loc, sizeof(double) * (size_t)s_loc, sizeof(double) * (size_t)s_loc, d,
+                              hipMemcpyDeviceToDevice, st));
+  FLGP_TRY(flgp_comm_all_gather(comm, pad.as<double>(), all.as<double>(), (size_t)smax * d, st));
+  long off = 0;
+  for (int q = 0; q < world; ++q) {
+    const int c = (int)hc[q];
+    if (c)
+      FLGP_HIP(hipMemcpy2DAsync(dU_out + off, sizeof(double) * (size_t)s_total, all.as<double>() + (size_t)q * smax * d,
+                                sizeof(double) * (size_t)smax, sizeof(double) * (size_t)c, d, hipMemcpyDeviceToDevice, st));
+    off += c;
+  }
+  FLGP_HIP(hipStreamSynchronize(st));     // (the temporaries die here)
+  return FLGP_OK;
+}
+
+extern "C" int flgp_dev_cluster_sizes(void *stream, const flgp_comm *comm, const double *dX_loc, int n_loc, int ldx, int d,
+                                      const double *dU, int ldu, int s, double *d_sizes_out) {
+  hipStream_t st = (hipStream_t)stream;
+  FLGP_REQUIRE(dX_loc && dU && d_sizes_out && n_loc >= 1 && s >= 1 && ldx >= n_loc && ldu >= s, "cluster_sizes: bad arguments");
+  const int dpad = flgp_dev_anchor_dpad(d);
+  FLGP_REQUIRE(dpad > 0, "kernels are built for 1 <= d <= %d (got %d)", FLGP_DMAX, d);
+  const int rows = flgp_dev_anchor_rows(s);
+  DevBuf Ut, uu, idx, cnt;
+  FLGP_TRY(Ut.alloc(sizeof(double) * (size_t)rows * dpad));
+  FLGP_TRY(uu.alloc(sizeof(double) * (size_t)rows));
+  FLGP_TRY(idx.alloc(sizeof(int) * (size_t)n_loc));
+  FLGP_TRY(cnt.alloc(sizeof(int) * (size_t)s));
+  FLGP_TRY(flgp_dev_anchor_prep(st, dU, s, ldu, d, Ut.as<double>(), uu.as<double>()));
+  FLGP_TRY(flgp_dev_knn(st, dX_loc, n_loc, ldx, d, Ut.as<double>(), uu.as<double>(), s, 1, idx.as<int>(), nullptr, n_loc));
+  FLGP_HIP(hipMemsetAsync(cnt.p, 0, sizeof(int) * (size_t)s, st));
+  hipLaunchKernelGGL(count_labels_kernel, dim3((unsigned)std::min<long>(2048, ((long)n_loc + 255) / 256)), dim3(256), 0, st, idx.as<int>(),
+                     (long)n_loc, s, cnt.as<int>());
+  hipLaunchKernelGGL(int_to_double_kernel, dim3(ceil_div(s, 256)), dim3(256), 0, st, cnt.as<int>(), s, d_sizes_out);
+  FLGP_TRY(check_launch("count_labels_kernel"));
+  FLGP_TRY(flgp_comm_all_reduce_sum(comm, d_sizes_out, (size_t)s, st));
+  FLGP_HIP(hipStreamSynchronize(st));
+  return FLGP_OK;
+}
+
+extern "C" int flgp_dev_heat_kernel_covariance_sharded(void *stream, const flgp_comm *comm, const double *dX_loc, int n_loc,
+                                                       int ldx, int d, long n_global, long row_lo, const double *dU, int ldu,
+                                                       int s, const double *d_sizes, int m, int r, double t, int K,
+                                                       const char *kernel, const char *gl, int root, double epsilon,
+                                                       double *dH_loc, int ldh, double *d_values_out, double *d_vectors_out,
+                                                       int ldv, int *info) {
+  hipStream_t st = (hipStream_t)stream;
+  int se = 0;
+  FLGP_TRY(parse_kernel(kernel, &se));
+  const int glc = flgp_parse_gl(gl);
+  if (glc < 0) return glc;
+  FLGP_REQUIRE(dX_loc && dU && dH_loc, "sharded covariance: null pointer");
+  FLGP_REQUIRE(n_loc >= 1 && ldx >= n_loc && d >= 1 && s >= 1 && ldu >= s, "sharded covariance: bad shape n_loc=%d d=%d s=%d", n_loc, d, s);
+  FLGP_REQUIRE(n_global >= n_loc && row_lo >= 0 && row_lo + n_loc <= n_global, "sharded covariance: rows [%ld, %ld) do not lie in [0, %ld)",
+               row_lo, row_lo + n_loc, n_global);
+  FLGP_REQUIRE(m >= 1 && (long)m <= n_global && ldh >= n_loc, "sharded covariance: need 1 <= m <= n and ldh >= n_loc");
+  FLGP_REQUIRE(glc != FLGP_GL_CLUSTER_NORMALIZED || d_sizes, "gl=\"cluster-normalized\" needs the cluster sizes");
+  FLGP_REQUIRE(!d_vectors_out || ldv >= n_loc, "sharded covariance: ldv < n_loc");
+  const int dpad = flgp_dev_anchor_dpad(d);
+  FLGP_REQUIRE(dpad > 0, "kernels are built for 1 <= d <= %d (got %d)", FLGP_DMAX, d);
+  if (K < 0) K = s;
+  Sim S;
+  S.n = n_loc; S.d = d; S.s = s; S.ldx = ldx; S.comm = comm; S.n_global = n_global; S.sizes = d_sizes;
+  S.X.borrow(dX_loc);
+  const int rows = flgp_dev_anchor_rows(s);
+  FLGP_TRY(S.Ut.alloc(sizeof(double) * (size_t)rows * dpad));
+  FLGP_TRY(S.uu.alloc(sizeof(double) * (size_t)rows));
+  FLGP_TRY(flgp_dev_anchor_prep(st, dU, s, ldu, d, S.Ut.as<double>(), S.uu.as<double>()));
+  FLGP_TRY(cross_similarity(S, st, r, se, glc, epsilon, d));
+  Spectrum P;
+  FLGP_TRY(spectrum(S, st, K, root, P, info));
+  // exchange 4: the training block V[0:m] (m x K), zero where this rank owns no row of it, summed over the ranks
+  DevBuf V1, work;
+  FLGP_TRY(V1.alloc(sizeof(double) * (size_t)m * K));
+  FLGP_HIP(hipMemsetAsync(V1.p, 0, sizeof(double) * (size_t)m * K, st));
+  if (row_lo < m) {
+    const long cnt = std::min<long>(row_lo + n_loc, (long)m) - row_lo;
+    FLGP_HIP(hipMemcpy2DAsync(V1.as<double>() + row_lo, sizeof(double) * (size_t)m, P.vectors.p, sizeof(double) * (size_t)n_loc,
+                              sizeof(double) * (size_t)cnt, K, hipMemcpyDeviceToDevice, st));
+  }
+  FLGP_TRY(flgp_comm_all_reduce_sum(comm, V1.as<double>(), (size_t)m * K, st));
+  FLGP_TRY(work.alloc(flgp_dev_hk_workspace(n_loc, m, K, 0)));
+  FLGP_TRY(flgp_dev_hk(st, P.values.as<double>(), K, t, P.vectors.as<double>(), n_loc, nullptr, 0, n_loc, V1.as<double>(), m, nullptr, 0,
+                       m, dH_loc, ldh, work.as<double>()));
+  if (d_values_out) FLGP_HIP(hipMemcpyAsync(d_values_out, P.values.p, sizeof(double) * (size_t)K, hipMemcpyDeviceToDevice, st));
+  if (d_vectors_out)
+    FLGP_HIP(hipMemcpy2DAsync(d_vectors_out, sizeof(double) * (size_t)ldv, P.vectors.p, sizeof(double) * (size_t)n_loc,
+                              sizeof(double) * (size_t)n_loc, K, hipMemcpyDeviceToDevice, st));
+  FLGP_HIP(hipStreamSynchronize(st));
+  return FLGP_OK;
+}
+
+extern "C" int flgp_heat_kernel_covariance_multi(const double *X_all, int n, int m, int d, const double *U, int s, int ucols,
+                                                 int r, double t, int K, const char *kernel, const char *gl, int root,
+                                                 double epsilon, int ndev, const int *devices, double *H) {
+  int se = 0;
+  FLGP_TRY(parse_kernel(kernel, &se));
+  const int glc = flgp_parse_gl(gl);
+  if (glc < 0) return glc;
+  FLGP_REQUIRE(X_all && U && H && devices, "heat_kernel_covariance_multi: null pointer");
+  FLGP_REQUIRE(ndev >= 1 && ndev <= 16 && n >= ndev, "heat_kernel_covariance_multi: need 1 <= ndev <= 16 ranks and n >= ndev");
+  FLGP_REQUIRE(m >= 1 && m <= n && d >= 1 && s >= 1, "heat_kernel_covariance_multi: bad shape");
+  FLGP_REQUIRE(ucols == d || ucols == d + 1, "U must have d or d+1 columns (d=%d, got %d)", d, ucols);
+  FLGP_REQUIRE(glc != FLGP_GL_CLUSTER_NORMALIZED || ucols == d + 1,
+               "gl=\"cluster-normalized\" needs the cluster sizes in column d+1 of U (the reference reads out of bounds here)");
+  if (ndev == 1) {
+    FLGP_TRY(flgp_set_device(devices[0]));
+    return flgp_heat_kernel_covariance(X_all, n, m, d, U, s, ucols, r, t, K, kernel, gl, root, epsilon, H);
+  }
+  // transport: RCCL when every rank has a device of its own and the library loads; else the in-process backend (ranks
+  // that share a device, or no RCCL) with peer access between the devices involved
+  bool distinct = true;
+  for (int a = 0; a < ndev; ++a)
+    for (int b = a + 1; b < ndev; ++b) distinct = distinct && devices[a] != devices[b];
+  std::vector<flgp_comm *> comms((size_t)ndev, nullptr);
+  bool rccl = false;
+  if (distinct && tuning("multi_rccl", 1)) rccl = flgp_comm_rccl_init_all(ndev, devices, comms.data()) == FLGP_OK;
+  if (!rccl) {
+    FLGP_TRY(flgp_comm_inproc_create(ndev, comms.data()));
+    for (int a = 0; a < ndev; ++a)
+      for (int b = 0; b < ndev; ++b)
+        if (devices[a] != devices[b]) {
+          int can = 0;
+          if (hipDeviceCanAccessPeer(&can, devices[a], devices[b]) != hipSuccess || !can) {
+            for (auto c : comms) flgp_comm_destroy(c);
+            set_error("heat_kernel_covariance_multi: device %d cannot read device %d's memory and RCCL is not available", devices[a], devices[b]);
+            return FLGP_ERR_UNSUPPORTED;
+          }
+          if (hipSetDevice(devices[a]) == hipSuccess) {
+            const hipError_t e = hipDeviceEnablePeerAccess(devices[b], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { (void)hipGetLastError(); }
+            (void)hipGetLastError();
+          }
+        }
+  }
+  std::vector<int> rcs((size_t)ndev, FLGP_OK);
+  std::vector<std::string> msgs((size_t)ndev);
+  auto rank_main = [&](int q) -> int {
+    FLGP_HIP(hipSetDevice(devices[q]));
+    Stream st;
+    FLGP_TRY(st.create());
+    const long base = n / ndev, rem = n % ndev;
+    const long lo = q * base + std::min<long>(q, rem), n_loc = base + (q < rem ? 1 : 0);
+    DevBuf dX, dUall, dHl;
+    FLGP_TRY(dX.alloc(sizeof(double) * (size_t)n_loc * d));
+    FLGP_TRY(dUall.alloc(sizeof(double) * (size_t)s * ucols));
+    FLGP_TRY(dHl.alloc(sizeof(double) * (size_t)n_loc * m));
+    // rows [lo, lo + n_loc) of every column of X_all
+    FLGP_HIP(hipMemcpy2DAsync(dX.p, sizeof(double) * (size_t)n_loc, X_all + lo, sizeof(double) * (size_t)n, sizeof(double) * (size_t)n_loc, d,
+                              hipMemcpyHostToDevice, st.s));
+    FLGP_TRY(h2d(dUall.p, U, sizeof(double) * (size_t)s * ucols, st.s));
+    {
+      InputCheck ck;
+      FLGP_TRY(ck.begin(st.s));
+      FLGP_TRY(ck.finite(st.s, dX.as<double>(), n_loc * d));
+      FLGP_TRY(ck.finite(st.s, dUall.as<double>(), (long)s * ucols));
+      FLGP_TRY(ck.verdict(st.s, "points / anchors"));
+    }
+    const double *sizes = (ucols == d + 1) ? dUall.as<double>() + (size_t)d * s : nullptr;
+    FLGP_TRY(flgp_dev_heat_kernel_covariance_sharded(st.s, comms[q], dX.as<double>(), (int)n_loc, (int)n_loc, d, (long)n, lo, dUall.as<double>(), s,
+                                                     s, sizes, m, r, t, K, kernel, gl, root, epsilon, dHl.as<double>(), (int)n_loc, nullptr,
+                                                     nullptr, 0, nullptr));
+    FLGP_HIP(hipMemcpy2DAsync(H + lo, sizeof(double) * (size_t)n, dHl.p, sizeof(double) * (size_t)n_loc, sizeof(double) * (size_t)n_loc, m,
+                              hipMemcpyDeviceToHost, st.s));
+    FLGP_HIP(hipStreamSynchronize(st.s));
+    return FLGP_OK;
+  };
+  std::vector<std::thread> th;
+  for (int q = 0; q < ndev; ++q)
+    th.emplace_back([&, q]() {
+      rcs[q] = rank_main(q);
+      if (rcs[q] != FLGP_OK) {
+        msgs[q] = flgp_last_error();
+        if (comms[q] && comms[q]->abort) comms[q]->abort(comms[q]->ctx);    // the others must not wait for this rank for ever
+      }
+    });
+  for (auto &x : th) x.join();
+  for (auto c : comms) flgp_comm_destroy(c);
+  for (int q = 0; q < ndev; ++q)
+    if (rcs[q] != FLGP_OK && msgs[q].find("aborted by another rank") == std::string::npos) { set_error("rank %d: %s", q, msgs[q].c_str()); return rcs[q]; }
+  for (int q = 0; q < ndev; ++q)
+    if (rcs[q] != FLGP_OK) { set_error("rank %d: %s", q, msgs[q].c_str()); return rcs[q]; }
   return FLGP_OK;
 }
 

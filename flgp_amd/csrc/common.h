@@ -47,14 +47,43 @@ inline int hip_fail(hipError_t e, const char *what, const char *file, int line) 
 
 inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Device memory of the entry points comes from a small cache (core.hip): hipMalloc / hipFree cost 50-500 us each and an
+// entry point makes dozens (2.7 ms of a 34 ms call at BASELINE configs[2]); a block that is given back is kept, up to
+// `pool_max_mb` (default 16 GB) per process, and handed to the next request of the same size on the same device.  Giving
+// back synchronises the device first -- exactly what the hipFree it replaces did -- so nothing in flight can still use
+// the block when its next owner writes to it.  Blocks above 4 GB bypass the cache.  flgp_dev_pool_release() empties it.
+void *pool_take(int dev, size_t bytes);                 // nullptr: nothing of that size cached
+bool pool_give(int dev, void *p, size_t bytes);         // false: not kept (the caller frees)
+
 // RAII device buffer for the host-pointer entry points
 struct DevBuf {
   void *p = nullptr;
-  ~DevBuf() { if (p) (void)hipFree(p); }
+  bool owned = true;
+  size_t cap = 0;       // bytes as allocated (rounded), for the cache
+  int dev = -1;
+  ~DevBuf() { release(); }
+  void release() {
+    if (p && owned) {
+      bool kept = false;
+      if (cap && dev >= 0) { (void)hipDeviceSynchronize(); kept = pool_give(dev, p, cap); }
+      if (!kept) (void)hipFree(p);
+    }
+    p = nullptr; cap = 0; dev = -1;
+  }
+  void borrow(const void *q) { release(); p = (void *)q; owned = false; }   // the caller's device memory: never freed here
   int alloc(size_t bytes) {
     if (bytes == 0) bytes = 8;
+    release();
+    owned = true;
+    bytes = (bytes + 255) / 256 * 256;
+    int d = 0;
+    if (hipGetDevice(&d) == hipSuccess && bytes <= ((size_t)4 << 30)) {
+      p = pool_take(d, bytes);
+      if (p) { cap = bytes; dev = d; return FLGP_OK; }
+    }
     hipError_t e = hipMalloc(&p, bytes);
     if (e != hipSuccess) { p = nullptr; set_error("hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e)); return FLGP_ERR_NOMEM; }
+    if (bytes <= ((size_t)4 << 30)) { cap = bytes; dev = d; }
     return FLGP_OK;
   }
   template <class T> T *as() { return (T *)p; }

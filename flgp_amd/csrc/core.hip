@@ -62,9 +62,52 @@ void prof_end(int idx, hipStream_t st) {
   if (idx < (int)g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[idx].e1, st);
 }
 
+// ---- device memory cache (common.h, DevBuf) ----
+static std::mutex g_pool_mu;
+static std::multimap<std::pair<int, size_t>, void *> g_pool;
+static size_t g_pool_bytes = 0;
+
+void *pool_take(int dev, size_t bytes) {
+  if (tuning("pool", 1) == 0) return nullptr;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  auto it = g_pool.find(std::make_pair(dev, bytes));
+  if (it == g_pool.end()) return nullptr;
+  void *p = it->second;
+  g_pool.erase(it);
+  g_pool_bytes -= bytes;
+  return p;
+}
+
+bool pool_give(int dev, void *p, size_t bytes) {
+  if (tuning("pool", 1) == 0) return false;
+  const size_t cap = (size_t)tuning("pool_max_mb", 16384) << 20;
+  std::lock_guard<std::mutex> lk(g_pool_mu);
+  if (g_pool_bytes + bytes > cap) return false;
+  g_pool.emplace(std::make_pair(dev, bytes), p);
+  g_pool_bytes += bytes;
+  return true;
+}
+
 }  // namespace flgp
 
 using namespace flgp;
+
+extern "C" size_t flgp_dev_pool_release(void) {
+  std::vector<std::pair<int, void *>> blocks;
+  size_t bytes = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_pool_mu);
+    for (auto &kv : g_pool) blocks.emplace_back(kv.first.first, kv.second);
+    bytes = g_pool_bytes;
+    g_pool.clear();
+    g_pool_bytes = 0;
+  }
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  for (auto &b : blocks) { (void)hipSetDevice(b.first); (void)hipFree(b.second); }
+  (void)hipSetDevice(cur);
+  return bytes;
+}
 
 extern "C" void flgp_prof_enable(int on) {
   std::lock_guard<std::mutex> lk(g_prof_mu);

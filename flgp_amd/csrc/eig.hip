@@ -1346,11 +1346,15 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     return rotate(Yin, w.W, Qout);
   };
 
-  // ---- start block, orthonormalised (uniform random: condition ~ (sqrt s + sqrt b) / (sqrt s - sqrt b), and orth()
-  //      iterates to convergence by itself, so once is enough).  Four s x b buffers rotate through the roles
-  //      Q (orthonormal block) and three free ones.
+  // ---- start block: uniform random columns.  NOT orthonormalised (round 3): iteration 0 forms no Rayleigh-Ritz
+  //      matrix -- it filters the block as it is on a-priori bounds, and a filter is linear -- and the block that comes out
+  //      of the filter is orthonormalised anyway; a uniform random s x b block has condition
+  //      ~ (sqrt s + sqrt b) / (sqrt s - sqrt b) (1.6 at BASELINE configs[2]), so nothing is lost but the 0.33 ms of a
+  //      Gram product, 24 Newton-Schulz launches and two host round trips.  (eig_start_orths = 1 / 2: the old behaviour.)
+  //      Four s x b buffers rotate through the roles Q (current block) and three free ones.
   double *Q = w.Q, *F[3] = {w.Y, w.Yp, w.Z};
-  hipLaunchKernelGGL(eig_init_q_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, st, F[0], s, b, s,
+  const int start_orths = tuning("eig_start_orths", 1);   // (0 was tried in round 3: the 0.33 ms it saves sat in the shadow of the set-up's host round trips -- mean over eight start blocks 15.97 vs 15.83 ms)
+  hipLaunchKernelGGL(eig_init_q_kernel, dim3(ceil_div(tot, 256)), dim3(256), 0, st, start_orths > 0 ? F[0] : Q, s, b, s,
                      (unsigned long long)tuning("eig_start_stream", 0));   // 0 = the documented start block; others: robustness runs
   FLGP_TRY(check_launch("eig_init_q_kernel"));
   // Rayleigh-Ritz on the random start block yields nothing but bounds, and poor ones (every Ritz value of a random
@@ -1366,13 +1370,18 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     FLGP_HIP(hipMemcpyAsync(h_apriori, w.apriori, sizeof(double) * 2 * APRIORI_BLOCKS, hipMemcpyDeviceToHost, st));
   }
   double cond = 0.0;
-  if (tuning("eig_start_orths", 1) >= 2) {
+  if (start_orths >= 2) {
     FLGP_TRY(orth(F[0], F[1], &cond));
     FLGP_TRY(orth(F[1], Q, &cond));
-  } else {
+  } else if (start_orths == 1) {
     FLGP_TRY(orth(F[0], Q, &cond));
+  } else if (!skip_rr0) {
+    // an iteration 0 WITH Rayleigh-Ritz needs an orthonormal block
+    FLGP_TRY(orth(Q, F[0], &cond));
+    std::swap(Q, F[0]);
   }
-  bsg_finish(bs);   // (the orthonormalisation has synchronised the stream: the set-up's bookkeeping has arrived)
+  FLGP_HIP(stream_wait(st));   // the set-up's bookkeeping (and the a-priori bounds) have arrived on the host
+  bsg_finish(bs);
 
   std::vector<double> theta(b), res(K);
   int gprods = 0, it = 0;

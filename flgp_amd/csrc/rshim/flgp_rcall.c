@@ -23,6 +23,7 @@
 #include <R.h>
 #include <Rinternals.h>
 #include <R_ext/Rdynload.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "flgp_hip.h"
@@ -285,9 +286,25 @@ SEXP FLGP_heat_kernel_covariance_cpp(SEXP XS, SEXP XnewS, SEXP sS, SEXP rS, SEXP
   SEXP U = PROTECT(subsample(Xall, s, as_cstr(list_get(modelsS, "subsample")), Rf_asInteger(nstartS)));
   PutRNGstate();
   SEXP H = PROTECT(Rf_allocMatrix(REALSXP, n, m));
-  chk(flgp_heat_kernel_covariance(REAL(Xall), n, m, d, REAL(U), s, Rf_ncols(U), r, Rf_asReal(tS), K,
-                                  as_cstr(list_get(modelsS, "kernel")), as_cstr(list_get(modelsS, "gl")),
-                                  Rf_asLogical(list_get(modelsS, "root")), Rf_asReal(epsilonS), REAL(H)));
+  /* FLGP_DEVICES="0,1,2,3" in the environment of the R session: the rows are sharded over those GPUs (one host thread
+   * each inside the library, RCCL over xGMI between them); unset or a single id: the one-GPU entry point */
+  int devs[16], ndev = 0;
+  const char *env = getenv("FLGP_DEVICES");
+  while (env && *env && ndev < 16) {
+    char *end = NULL;
+    const long v = strtol(env, &end, 10);
+    if (end == env) break;
+    devs[ndev++] = (int)v;
+    env = (*end == ',') ? end + 1 : end;
+  }
+  if (ndev > 1)
+    chk(flgp_heat_kernel_covariance_multi(REAL(Xall), n, m, d, REAL(U), s, Rf_ncols(U), r, Rf_asReal(tS), K,
+                                          as_cstr(list_get(modelsS, "kernel")), as_cstr(list_get(modelsS, "gl")),
+                                          Rf_asLogical(list_get(modelsS, "root")), Rf_asReal(epsilonS), ndev, devs, REAL(H)));
+  else
+    chk(flgp_heat_kernel_covariance(REAL(Xall), n, m, d, REAL(U), s, Rf_ncols(U), r, Rf_asReal(tS), K,
+                                    as_cstr(list_get(modelsS, "kernel")), as_cstr(list_get(modelsS, "gl")),
+                                    Rf_asLogical(list_get(modelsS, "root")), Rf_asReal(epsilonS), REAL(H)));
   UNPROTECT(5);
   return H;
 }

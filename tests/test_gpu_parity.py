@@ -1135,3 +1135,138 @@ def test_c4_full_size_row_sharded_two_ranks(tmp_path):
     for r in range(2):
         np.testing.assert_allclose(np.load(os.path.join(out, f"v_2_{r}.npy")), v1, rtol=EIG_RTOL)
     assert abs(v1[0] - 1.0) < 1e-6
+
+
+# ------------------------------------------------------------------------------ the sharded path behind the C ABI
+def _run_ranks(world, fn):
+    """Run fn(rank) on `world` host threads (the ranks of an in-process communicator) and return the results."""
+    import threading
+    out = [None] * world; err = [None] * world
+    def body(q):
+        try:
+            with torch.cuda.stream(torch.cuda.Stream(device="cuda:0")):
+                out[q] = fn(q)
+                torch.cuda.current_stream().synchronize()
+        except BaseException as e:      # noqa: BLE001
+            err[q] = e
+    th = [threading.Thread(target=body, args=(q,)) for q in range(world)]
+    for t in th: t.start()
+    for t in th: t.join()
+    for e in err:
+        if e is not None:
+            raise e
+    return out
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_c_abi_communicator_collectives(world):
+    """flgp_comm, in-process backend (csrc/comm.hip): ranks are host threads sharing the one card; all-reduce adds the
+    ranks' buffers in rank order (bit-identical on every rank), all-gather concatenates -- plus the two helpers built on
+    them, the ragged anchor gather and the global 1-NN cluster counts."""
+    L = _lib.lib()
+    comms = (ctypes.c_void_p * world)()
+    _lib.check(L.flgp_comm_inproc_create(world, comms))
+    rng = np.random.default_rng(world)
+    data = [rng.normal(size=100_003) for _ in range(world)]
+    n, d, s = 4000, 5, 37
+    X = synth.gaussian_mixture(n, d, components=4, seed=9)
+    cnts = [s // world + (1 if q < s % world else 0) for q in range(world)]
+    offs = np.concatenate([[0], np.cumsum(cnts)])
+    Uall = np.asfortranarray(X[np.sort(synth.random_anchor_rows(n, s, seed=9))])
+    from flgp_amd.pipeline import shard_bounds
+
+    def body(q):
+        st = torch.cuda.current_stream().cuda_stream
+        c = comms[q]
+        assert L.flgp_comm_rank(c) == q and L.flgp_comm_world(c) == world
+        buf = torch.from_numpy(data[q].copy()).cuda()
+        _lib.check(L.flgp_comm_all_reduce_sum(c, buf.data_ptr(), buf.numel(), st))
+        send = torch.from_numpy(data[q][:1000].copy()).cuda(); recv = torch.empty(1000 * world, dtype=torch.float64, device="cuda:0")
+        _lib.check(L.flgp_comm_all_gather(c, send.data_ptr(), recv.data_ptr(), 1000, st))
+        # anchors: rank q contributes rows offs[q]:offs[q+1] (column-major s_loc x d)
+        Ul = cm(Uall[offs[q]:offs[q + 1]])
+        Uo = torch.empty((d, s), dtype=torch.float64, device="cuda:0")
+        _lib.check(L.flgp_dev_gather_anchors(st, c, Ul.data_ptr(), cnts[q], d, Uo.data_ptr(), s))
+        lo, hi = shard_bounds(n, world, q)
+        Xl = cm(X[lo:hi])
+        sizes = torch.empty(s, dtype=torch.float64, device="cuda:0")
+        _lib.check(L.flgp_dev_cluster_sizes(st, c, Xl.data_ptr(), hi - lo, hi - lo, d, Uo.data_ptr(), s, s, sizes.data_ptr()))
+        torch.cuda.current_stream().synchronize()
+        return buf.cpu().numpy(), recv.cpu().numpy(), to_np_cm(Uo), sizes.cpu().numpy()
+
+    try:
+        res = _run_ranks(world, body)
+    finally:
+        for q in range(world):
+            L.flgp_comm_destroy(comms[q])
+    want = data[0].copy()
+    for q in range(1, world):
+        want = want + data[q]                                          # rank order
+    from oracle import flgp_oracle as O
+    sizes_o = np.bincount(O.knn(X, Uall, 1)[:, 0], minlength=s).astype(float)
+    for q in range(world):
+        np.testing.assert_array_equal(res[q][0], want)
+        np.testing.assert_array_equal(res[q][1], np.concatenate([data[z][:1000] for z in range(world)]))
+        np.testing.assert_array_equal(res[q][2], Uall)
+        np.testing.assert_array_equal(res[q][3], sizes_o)
+
+
+@pytest.mark.parametrize("devices", [[0, 0], [0, 0, 0]])
+def test_sharded_covariance_behind_the_c_abi(oracle, devices):
+    """flgp_heat_kernel_covariance_multi: the host boundary of the row-sharded path (what the R shim calls when
+    FLGP_DEVICES lists several GPUs).  Ranks = host threads, here sharing the one card through the in-process
+    communicator: k-NN / LAE / scalings per row block, column sums, packed Gram partials and the training block exchanged
+    inside the C library, eigensolve replicated.  Against the single-GPU entry point (rounding-level differences from the
+    association of the sums only) and the oracle."""
+    n, d, s, r, K, m, t = 7001, 6, 300, 6, 40, 333, 4.0
+    X, U0, U = make_case(n, d, s, r, seed=77)
+    models = dict(kernel="lae", gl="cluster-normalized", root=True)
+    H1 = api.heat_kernel_covariance_cpp(X[:m], X[m:], s, r, t, K, models, 1, 0.1, U=U)
+    Hm = api.heat_kernel_covariance_cpp(X[:m], X[m:], s, r, t, K, models, 1, 0.1, U=U, devices=devices)
+    assert Hm.shape == H1.shape == (n, m)
+    assert np.abs(Hm - H1).max() <= H_RTOL * np.abs(H1).max(), np.abs(Hm - H1).max() / np.abs(H1).max()
+    Ho = oracle.heat_kernel_covariance(X[:m], X[m:], U, r, t, K=K)
+    assert np.abs(Hm - Ho).max() <= H_RTOL * np.abs(Ho).max()
+    # the SE kernel and the plain random-walk Laplacian go through the same exchanges
+    models = dict(kernel="se", gl="rw", root=False)
+    H1 = api.heat_kernel_covariance_cpp(X[:m], X[m:], s, r, t, K, models, 1, 0.7, U=U)
+    Hm = api.heat_kernel_covariance_cpp(X[:m], X[m:], s, r, t, K, models, 1, 0.7, U=U, devices=devices)
+    assert np.abs(Hm - H1).max() <= H_RTOL * np.abs(H1).max()
+    with pytest.raises(api.FlgpError):                                  # an error on the ranks comes back, nobody hangs
+        api.heat_kernel_covariance_cpp(X[:m], X[m:], s, s + 1, t, K, models, 1, 0.7, U=U, devices=devices)
+
+
+def test_rccl_backend_loads_and_runs_on_one_rank(stages):
+    """The RCCL backend (librccl.so through dlopen) with a world of one -- all a one-GPU box can hold, RCCL refuses two
+    ranks on one device: communicator creation, both collectives (identities on one rank) and the sharded device entry
+    point on top of it, against the stage-by-stage driver."""
+    L = _lib.lib()
+    comms = (ctypes.c_void_p * 1)()
+    dev = (ctypes.c_int * 1)(0)
+    _lib.check(L.flgp_comm_rccl_init_all(1, dev, comms))
+    idbuf = (ctypes.c_char * 128)()
+    _lib.check(L.flgp_comm_rccl_unique_id(idbuf))
+    try:
+        st = torch.cuda.current_stream().cuda_stream
+        x = torch.arange(1000, dtype=torch.float64, device="cuda:0")
+        _lib.check(L.flgp_comm_all_reduce_sum(comms[0], x.data_ptr(), 1000, st))
+        y = torch.empty(1000, dtype=torch.float64, device="cuda:0")
+        _lib.check(L.flgp_comm_all_gather(comms[0], x.data_ptr(), y.data_ptr(), 1000, st))
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(x.cpu().numpy(), np.arange(1000.0))
+        np.testing.assert_array_equal(y.cpu().numpy(), np.arange(1000.0))
+        n, d, s, r, K, m, t = 5000, 4, 256, 5, 32, 200, 3.0
+        X, U0, U = make_case(n, d, s, r, seed=5)
+        dX = cm(X); dU = cm(U0); sizes = torch.from_numpy(U[:, d].copy()).cuda()
+        H = torch.empty((m, n), dtype=torch.float64, device="cuda:0")
+        vals = torch.empty(K, dtype=torch.float64, device="cuda:0")
+        _lib.check(L.flgp_dev_heat_kernel_covariance_sharded(st, comms[0], dX.data_ptr(), n, n, d, n, 0, dU.data_ptr(), s, s,
+                                                             sizes.data_ptr(), m, r, t, K, b"lae", b"cluster-normalized", 1, 0.1,
+                                                             H.data_ptr(), n, vals.data_ptr(), None, 0, None))
+        path = HeatKernelPath(stages)
+        res = path.run(dX, dU, PathConfig(s=s, r=r, K=K, t=t, m=m), n, 0, num_class=sizes)
+        np.testing.assert_allclose(vals.cpu().numpy(), res.values.cpu().numpy(), rtol=EIG_RTOL)
+        Hp = res.H.cpu().numpy()
+        assert np.abs(H.cpu().numpy() - Hp).max() <= H_RTOL * np.abs(Hp).max()
+    finally:
+        L.flgp_comm_destroy(comms[0])
