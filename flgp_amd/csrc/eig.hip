@@ -498,6 +498,163 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
 }
 
 // ------------------------------------------------------------------------------------------
+// The same visit for panels that do NOT fit LDS (b above ~1000: the full decomposition of a large Gram matrix, the
+// K == s branch of truncated_SVD_cpp, src/TruncatedSVD.cpp:17-20, for s up to 16384).  The 32 columns of the pair are
+// streamed through LDS in chunks of JS_CHUNK rows: pass 1 accumulates the 32 x 32 Gram block on the matrix cores (one
+// accumulator per wave, carried across the chunks; the sixteen partial tiles are added in a fixed order), the small
+// eigenproblem is solved in LDS as above (one full cyclic sweep of two-sided rotations), pass 2 streams the B panel and
+// then the V panel again and applies the accumulated rotation by MFMA.  Per visit the B panel is read twice and
+// written once, the V panel read and written once: at s = 5000 a round of 156 visits moves ~1 GB (0.2 ms), a sweep
+// of 312 rounds takes ~60 ms and the decomposition converges in 8-10 sweeps -- well under a second for what the
+// reference does with a dense BDCSVD of the n x s matrix.
+// ------------------------------------------------------------------------------------------
+constexpr int JS_CHUNK = 256;      // rows per chunk: 32 x 258 doubles of LDS
+
+__global__ __launch_bounds__(1024) void jac_stream_kernel(double *__restrict__ B, double *__restrict__ V, int b, int ldb,
+                                                          int nbc, int round, double tol, int *__restrict__ flags) {
+  constexpr int NLOC = 32, WB = 16, NP = 16, NT16 = 2, TILES = 4, KP = 4;
+  constexpr int CP = JS_CHUNK + 2;          // LDS column stride
+  __shared__ double P[NLOC * CP];
+  __shared__ double Gm[NLOC * NLOC], Wm[NLOC * NLOC], G2[NLOC * NLOC], W2[NLOC * NLOC];
+  __shared__ double part[TILES * KP][16 * 16];
+  __shared__ double cc[NLOC], dd[NLOC];
+  __shared__ int pr[NLOC];
+  __shared__ int round_rot[3];
+  __shared__ int visit_rot;
+  if (flags[1]) return;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid < 3) round_rot[tid] = 0;
+  if (tid == 0) visit_rot = 0;
+  int I, J;
+  rr_pair(nbc, round, blockIdx.x, I, J);
+  const int cI = I * WB, cJ = J * WB;
+  if (cI >= b) return;
+  auto gcol = [&](int c) { return (c < WB) ? cI + c : cJ + (c - WB); };
+  const int nchunk = (b + JS_CHUNK - 1) / JS_CHUNK;
+  auto load_chunk = [&](const double *M, int r0) {       // rows r0 .. r0 + JS_CHUNK of the 32 columns (zeros outside the matrix)
+    for (int c = wave; c < NLOC; c += 16) {
+      const int gc = gcol(c);
+      for (int i = lane; i < JS_CHUNK; i += 64) P[c * CP + i] = (gc < b && r0 + i < b) ? M[(size_t)gc * ldb + r0 + i] : 0.0;
+    }
+  };
+  auto store_chunk = [&](double *M, int r0) {
+    for (int c = wave; c < NLOC; c += 16) {
+      const int gc = gcol(c);
+      if (gc < b)
+        for (int i = lane; i < JS_CHUNK; i += 64)
+          if (r0 + i < b) M[(size_t)gc * ldb + r0 + i] = P[c * CP + i];
+    }
+  };
+  // ---- pass 1: Gram block; wave = (tile, row part), each part a quarter of every chunk
+  {
+    const int tile = wave % TILES, kp = wave / TILES;
+    const int tp = tile / NT16, tq = tile % NT16;
+    jd4 acc = jd4{0.0, 0.0, 0.0, 0.0};
+    const double *pa = P + (tp * 16 + (lane & 15)) * CP + (lane >> 4);
+    const double *pb = P + (tq * 16 + (lane & 15)) * CP + (lane >> 4);
+    constexpr int rows = JS_CHUNK / KP;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      __syncthreads();
+      load_chunk(B, ch * JS_CHUNK);
+      __syncthreads();
+      for (int i0 = kp * rows; i0 < (kp + 1) * rows; i0 += 4)
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[i0], pb[i0], acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int reg = 0; reg < 4; ++reg) part[wave][((lane >> 4) + 4 * reg) * 16 + (lane & 15)] = acc[reg];
+  }
+  __syncthreads();
+  for (int e = tid; e < NLOC * NLOC; e += 1024) {
+    const int i = e / NLOC, j = e % NLOC;
+    const int tile = (i / 16) * NT16 + (j / 16), w = (i % 16) * 16 + (j % 16);
+    double g = part[tile][w];
+#pragma unroll
+    for (int kp = 1; kp < KP; ++kp) g += part[kp * TILES + tile][w];
+    Gm[e] = g;
+    Wm[e] = (i == j) ? 1.0 : 0.0;
+  }
+  __syncthreads();
+  // ---- one cyclic sweep of two-sided rotations on the 32 x 32 block (as in jac_block_kernel)
+  double *Gc = Gm, *Gn = G2, *Wc = Wm, *Wn = W2;
+  const double tol2 = tol * tol;
+  int rotations = 0;
+  for (int rr = 0; rr < NLOC - 1; ++rr) {
+    if (tid < NP) {
+      int p, q;
+      rr_pair(NLOC, rr, tid, p, q);
+      const double al = Gc[p * NLOC + p], be = Gc[q * NLOC + q], ga = Gc[p * NLOC + q];
+      double cs = 1.0, sn = 0.0;
+      if (ga * ga > tol2 * (al * be) && al > 0.0 && be > 0.0) {
+        const double dl = be - al;
+        const double r1 = rsqrt_nr(dl * dl + 4.0 * (ga * ga));
+        const double x2 = 0.5 + 0.5 * (__builtin_fabs(dl) * r1);
+        const double r2 = rsqrt_nr(x2);
+        cs = x2 * r2;
+        sn = (dl >= 0.0 ? ga : -ga) * (r1 * r2);
+        ++rotations;
+        round_rot[rr % 3] = 1;
+        visit_rot = 1;
+      }
+      cc[p] = cs; dd[p] = -sn; pr[p] = q;
+      cc[q] = cs; dd[q] = sn;  pr[q] = p;
+    }
+    if (tid == 0) round_rot[(rr + 2) % 3] = 0;
+    __syncthreads();
+    if (!round_rot[rr % 3]) continue;
+    for (int e = tid; e < NLOC * NLOC; e += 1024) {
+      const int i = e / NLOC, j = e % NLOC;
+      const int pi = pr[i], pj = pr[j];
+      const double ci = cc[i], di = dd[i], cj = cc[j], dj = dd[j];
+      Gn[e] = ci * (cj * Gc[i * NLOC + j] + dj * Gc[i * NLOC + pj]) + di * (cj * Gc[pi * NLOC + j] + dj * Gc[pi * NLOC + pj]);
+      Wn[e] = cj * Wc[i * NLOC + j] + dj * Wc[i * NLOC + pj];
+    }
+    __syncthreads();
+    double *t1 = Gc; Gc = Gn; Gn = t1;
+    double *t2 = Wc; Wc = Wn; Wn = t2;
+  }
+  __syncthreads();
+  if (!visit_rot) return;          // the 32 columns were orthogonal to the threshold already
+  if (Wc != Wm)
+    for (int e = tid; e < NLOC * NLOC; e += 1024) Wm[e] = Wc[e];
+  __syncthreads();
+  if (tid < NP && rotations) atomicAdd(&flags[0], rotations);
+  // ---- pass 2: P <- P Wm, chunk by chunk, for the B panel and then the V panel
+  auto apply_w = [&]() {
+    for (int rb = wave; rb < JS_CHUNK / 16; rb += 16) {
+      const int i0 = rb * 16;
+      double bf[NLOC / 4];
+#pragma unroll
+      for (int kk = 0; kk < NLOC / 4; ++kk) bf[kk] = P[(kk * 4 + (lane >> 4)) * CP + i0 + (lane & 15)];
+      jd4 acc2[NT16];
+#pragma unroll
+      for (int tc = 0; tc < NT16; ++tc) {
+        acc2[tc] = jd4{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int kk = 0; kk < NLOC / 4; ++kk) {
+          const double a = Wm[(kk * 4 + (lane >> 4)) * NLOC + tc * 16 + (lane & 15)];
+          acc2[tc] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, bf[kk], acc2[tc], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int tc = 0; tc < NT16; ++tc)
+#pragma unroll
+        for (int reg = 0; reg < 4; ++reg) P[(tc * 16 + (lane >> 4) + 4 * reg) * CP + i0 + (lane & 15)] = acc2[tc][reg];
+    }
+  };
+  for (int which = 0; which < 2; ++which) {
+    double *M = which == 0 ? B : V;
+    for (int ch = 0; ch < nchunk; ++ch) {
+      __syncthreads();
+      load_chunk(M, ch * JS_CHUNK);
+      __syncthreads();
+      apply_w();
+      __syncthreads();
+      store_chunk(M, ch * JS_CHUNK);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
 // b x b x b products of the orthonormalisation (Newton-Schulz: three per iteration, hundreds per
 // solve).  The tiled GEMM of gemm.hip needs split-K and a reduction launch to find 33 MFLOP of
 // parallelism in four 128 x 128 tiles (14 + 9 us); here every 16 x 16 tile of C is one wave, operands go
@@ -812,6 +969,13 @@ static JacobiPlan jacobi_plan(int b) {
       }
     }
   }
+  if (b > tuning("jacobi_stream_above", 1024) && tuning("jacobi_scalar", 0) == 0) {
+    // panels too long for LDS: streamed visits (jac_stream_kernel); any b (ragged rows and block columns are handled)
+    p.nloc = -1; p.w = 16; p.nbc = (b + 15) / 16;
+    if (p.nbc & 1) ++p.nbc;
+    p.nt = 1024; p.lds = 0;
+    return p;
+  }
   // 2w columns of B and of V, each b+16 doubles, must fit ~150 KB of LDS
   int w = (int)((150 * 1024) / (sizeof(double) * 4 * (size_t)(b + 16)));
   int pw = 1;
@@ -913,7 +1077,7 @@ static int jacobi_run(hipStream_t st, int b, EigWork &w, std::vector<double> &h_
   const JacobiPlan p = jacobi_plan(b);
   const void *kfn = p.nloc == 32 ? (const void *)jac_block_kernel<32>
                   : p.nloc == 16 ? (const void *)jac_block_kernel<16> : (const void *)jac_round_kernel;
-  if (p.lds > 48 * 1024)
+  if (p.nloc >= 0 && p.lds > 48 * 1024)
     FLGP_HIP(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p.lds));
   FLGP_HIP(hipMemsetAsync(w.flags, 0, sizeof(int) * 12, st));
   const bool to_convergence = sweep_limit < 0;
@@ -926,7 +1090,9 @@ static int jacobi_run(hipStream_t st, int b, EigWork &w, std::vector<double> &h_
   for (int sw = 0; sw < max_sweeps; ++sw) {
     for (int round = 0; round < p.nbc - 1; ++round) {
       const int cross = (round > 0 && sw >= cross_from) ? 1 : 0;
-      if (p.nloc == 32)
+      if (p.nloc < 0)
+        hipLaunchKernelGGL(jac_stream_kernel, dim3(p.nbc / 2), dim3(1024), 0, st, JB, JV, b, b, p.nbc, round, tol, w.flags);
+      else if (p.nloc == 32)
         hipLaunchKernelGGL(jac_block_kernel<32>, dim3(p.nbc / 2), dim3(1024), p.lds, st, JB, JV, b, b, p.nbc, round,
                            tol, w.flags, tuning("jacobi_local_sweeps", 1), cross);
       else if (p.nloc == 16)
@@ -1069,7 +1235,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   if (tol <= 0.0) tol = 5e-11;   // relative residual of every wanted pair (Spectra's own tolerance is 1e-10)
   const bool dense = eig_use_dense(s, K);
   const int b = dense ? s : eig_block_size(s, K);
-  FLGP_REQUIRE(!dense || s <= 4096, "eig: the full decomposition (K == s, or K close to s) is built for s <= 4096");
+  FLGP_REQUIRE(!dense || s <= 16384, "eig: the full decomposition (K == s, or K close to s) is built for s <= 16384");
 
   // carve the workspace
   EigWork w;
@@ -1681,7 +1847,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
     // and unwanted eigenvalues coincide -- never meets the residual test.  While the full decomposition is affordable
     // (s <= 4096) it is taken instead, with its own workspace: any orthonormal basis of a degenerate eigenspace is a
     // valid answer, and the Jacobi route always delivers one.
-    if (s <= 4096 && tuning("eig_dense_fallback", 1)) {
+    if (s <= 8192 && tuning("eig_dense_fallback", 1)) {
       DevBuf fw, fvals, fV;
       const size_t fb = eig_workspace_bytes(s, s);
       FLGP_TRY(fw.alloc(fb));

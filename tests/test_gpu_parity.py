@@ -659,8 +659,22 @@ def test_end_to_end_c1_like(oracle):
     assert H.shape == (4800, 100)
     assert np.abs(H - Ho).max() <= H_RTOL * np.abs(Ho).max()
     em = api.lae_eigenmap(X, 600, r=3, ndim=4, U=U)
-    vals, _ = oracle.heat_kernel_spectrum(X, U, 3, 4, gl="cluster-normalized", root=True)
+    vals, vecs_o = oracle.heat_kernel_spectrum(X, U, 3, 4, gl="cluster-normalized", root=True)
     np.testing.assert_allclose(em["eigenvalues"], 1 - vals, rtol=0, atol=1e-10)
+    # the eigenvectors as well (a14): lae_eigenmap's embedding is the n x ndim block of U sqrt(n).  Individual vectors are
+    # defined up to sign (and up to rotation inside a cluster of equal eigenvalues), so they are compared as a SUBSPACE --
+    # |(I - Vo Vo^T / n) V| / sqrt(n) -- and, column by column after the sign is fixed, wherever the eigenvalue is
+    # separated from its neighbours by more than 1e-6
+    Vd = em["eigenvectors"]; n_ = Vd.shape[0]
+    assert Vd.shape == vecs_o.shape == (n_, 4)
+    resid = Vd - vecs_o @ (vecs_o.T @ Vd) / n_
+    assert np.abs(resid).max() / np.sqrt(n_) < 1e-9 and np.linalg.norm(resid) / np.sqrt(n_) < 1e-8
+    np.testing.assert_allclose(Vd.T @ Vd / n_, np.eye(4), atol=1e-9)
+    gaps = np.minimum(np.abs(np.diff(vals, prepend=np.inf)), np.abs(np.diff(vals, append=-np.inf)))
+    for k in range(4):
+        if gaps[k] > 1e-6:
+            sgn = np.sign(Vd[:, k] @ vecs_o[:, k])
+            assert np.abs(sgn * Vd[:, k] - vecs_o[:, k]).max() < 1e-8 / gaps[k] * 1e-2 + 1e-9, k
 
 
 def test_resident_eigenpair_matches_host_path(oracle):
@@ -1270,3 +1284,26 @@ def test_rccl_backend_loads_and_runs_on_one_rank(stages):
         assert np.abs(H.cpu().numpy() - Hp).max() <= H_RTOL * np.abs(Hp).max()
     finally:
         L.flgp_comm_destroy(comms[0])
+
+
+def test_r_default_k_minus_one_past_4096_anchors(oracle):
+    """heat_kernel_covariance_rcpp's default K = -1 (R/Fit.R:760) means K = s: truncated_SVD_cpp takes its dense BDCSVD
+    branch (src/TruncatedSVD.cpp:17-20).  Here that is the full Jacobi decomposition of the s x s Gram matrix, which
+    rounds 1-2 only built for s <= 4096; beyond it the panels are streamed through LDS (jac_stream_kernel).  s = 4500:
+    every eigenvalue against LAPACK on the oracle's Gram matrix, V^T V = n I for all 4500 columns, and the covariance
+    against the oracle's dense-SVD route."""
+    n, d, s, r, m, t = 24000, 4, 4500, 4, 300, 3.0
+    X, U0, U = make_case(n, d, s, r, seed=4500)
+    models = dict(kernel="lae", gl="cluster-normalized", root=True)
+    H = api.heat_kernel_covariance_rcpp(X[:m], X[m:], s, r, t, U=U)          # K = -1
+    Ho = oracle.heat_kernel_covariance(X[:m], X[m:], U, r, t, K=-1)
+    assert H.shape == Ho.shape == (n, m)
+    assert np.abs(H - Ho).max() <= H_RTOL * np.abs(Ho).max(), np.abs(H - Ho).max() / np.abs(Ho).max()
+    ep = api.heat_kernel_spectrum_cpp(X[:m], X[m:], s, r, -1, models, U=U)
+    ei, zn = oracle.cross_similarity(X, U, r, gl="cluster-normalized")
+    av, _ = oracle.scale_A(ei, zn, s)
+    w = np.linalg.eigvalsh(oracle.gram(ei, av, s))[::-1]
+    assert ep.values.shape == (s,) and w[-1] > 1e-8
+    np.testing.assert_allclose(ep.values ** 2, w, rtol=1e-9, atol=0)
+    VtV = ep.vectors.T @ ep.vectors / n
+    assert np.abs(VtV - np.eye(s)).max() < 1e-7
