@@ -33,27 +33,40 @@ __global__ __launch_bounds__(1024) void chol_solve_kernel(double *__restrict__ A
     }
     __syncthreads();
   }
-  if (bad) { if (tid == 0) flag[0] = 1; return; }
-  // L y = b, then L^T x = y: a thread per right-hand side
-  for (int c = tid; c < nrhs; c += 1024) {
-    double *b = B + (size_t)c * N;
-    for (int i = 0; i < N; ++i) {
-      double acc = b[i];
-      for (int k = 0; k < i; ++k) acc -= A[(size_t)k * N + i] * b[k];
-      b[i] = acc / A[(size_t)i * N + i];
-    }
-    for (int i = N - 1; i >= 0; --i) {
-      double acc = b[i];
-      const double *li = A + (size_t)i * N;       // column i of L = row i of L^T
-      for (int k = i + 1; k < N; ++k) acc -= li[k] * b[k];
-      b[i] = acc / li[i];
-    }
+  if (bad && tid == 0) flag[0] = 1;
+}
+
+// B <- A^-1 B with the factor chol_solve_kernel left in A: L y = b, then L^T x = y, a thread per right-hand side, the
+// right-hand sides spread over the whole grid.  (Round 2 solved them inside the factorisation's one workgroup:
+// posterior_covariance_regression with m <= K passes m_new right-hand sides, and m_new ~ n = 1e6 of them on a single CU
+// took minutes -- ADVICE r02.  The arithmetic per right-hand side is unchanged, so are the bits.)
+__global__ __launch_bounds__(128) void chol_apply_kernel(const double *__restrict__ A, int N, double *__restrict__ B, int nrhs,
+                                                         const int *__restrict__ flag) {
+  if (flag[0]) return;
+  const long c = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= nrhs) return;
+  double *b = B + (size_t)c * N;
+  for (int i = 0; i < N; ++i) {
+    double acc = b[i];
+    for (int k = 0; k < i; ++k) acc -= A[(size_t)k * N + i] * b[k];
+    b[i] = acc / A[(size_t)i * N + i];
+  }
+  for (int i = N - 1; i >= 0; --i) {
+    double acc = b[i];
+    const double *li = A + (size_t)i * N;       // column i of L = row i of L^T
+    for (int k = i + 1; k < N; ++k) acc -= li[k] * b[k];
+    b[i] = acc / li[i];
   }
 }
 
 int chol_solve(hipStream_t st, double *dA, int N, double *dB, int nrhs, int *d_flag) {
   hipLaunchKernelGGL(chol_solve_kernel, dim3(1), dim3(1024), 0, st, dA, N, dB, nrhs, d_flag);
-  return check_launch("chol_solve_kernel");
+  FLGP_TRY(check_launch("chol_solve_kernel"));
+  if (nrhs > 0) {
+    hipLaunchKernelGGL(chol_apply_kernel, dim3(ceil_div(nrhs, 128)), dim3(128), 0, st, dA, N, dB, nrhs, d_flag);
+    FLGP_TRY(check_launch("chol_apply_kernel"));
+  }
+  return FLGP_OK;
 }
 
 // lam_k = 1 - values_k ; ls = exp(-t lam / 2), l = exp(-t lam)      (src/Predict.cpp:60,64; src/Utils.cpp:220,224)

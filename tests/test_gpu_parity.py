@@ -742,6 +742,28 @@ def test_resident_regression_prediction_and_posterior_variance(oracle, m, K, q):
         rp.posterior_covariance_regression(np.arange(m), np.arange(5), K, (1.0, 0.0), 0.0)       # var + sigma = 0
     rp.free()
 
+def test_posterior_variance_many_new_rows(oracle):
+    """posterior_covariance_regression's m <= K branch solves one m x m system per NEW row (src/Utils.cpp:227-237): with
+    m_new ~ n the right-hand sides must be spread over the chip (round 2 ran them all inside the factorisation's single
+    workgroup -- minutes at n = 1e6).  120 000 new rows against the numpy restatement."""
+    import time
+    n, m, K = 120_000, 60, 80
+    X, U0, U = make_case(n, 3, 300, 5, seed=12)
+    models = dict(kernel="lae", gl="cluster-normalized", root=True)
+    rp = api.heat_kernel_spectrum_resident(X[:m], X[m:], 300, 5, K, models, U=U)
+    ep = rp.to_host()
+    idx0 = np.arange(m); idx1 = np.arange(m, n)
+    t, noise, sigma = 5.0, 0.05, 1e-3
+    t0 = time.perf_counter()
+    gotv = rp.posterior_covariance_regression(idx0, idx1, K, (t, noise), sigma)
+    dt = time.perf_counter() - t0
+    refv = oracle.np_posterior_covariance_regression(ep.values, ep.vectors, idx0, idx1, K, (t, noise), sigma)
+    prior = ((ep.vectors[idx1, :K] ** 2) * np.exp(-t * (1.0 - ep.values[:K]))).sum(1).max()
+    np.testing.assert_allclose(gotv, refv, rtol=0, atol=1e-9 * np.abs(refv).max() + 2e-15 * prior * m / (noise + sigma))
+    assert dt < 5.0, dt
+    rp.free()
+
+
 @pytest.mark.parametrize("n,d,s,a2,K,seed", [(3000, 3, 300, 1.0, 30, 0), (5000, 7, 500, 0.5, 60, 1),
                                               (2000, 16, 257, 10.0, 20, 2), (700, 2, 64, 0.1, 64 // 4, 3)])
 def test_nystrom_eigenpair(oracle, n, d, s, a2, K, seed):
