@@ -44,12 +44,28 @@ __device__ __forceinline__ double group_bcast(double v, int j) {
   }
 }
 
+// Iteration-budget passes (round 3).  The iteration count is data dependent -- mean 10.4 per point at BASELINE
+// configs[2], mean of the per-wave maximum 20 -- and a wave runs until its slowest point has converged: half of the lane
+// cycles are spent on points that are done.  So the work is cut in two: pass 1 gives every point `t_cut` iterations; a
+// point that has not met the stop test by then parks its state (z_prev, z_curr, the exponent of beta: 2r + 1 doubles; the
+// momentum sequence is the same for every point and indexed by t) in a list, and pass 2 runs over the COMPACTED list
+// from iteration t_cut on.  The iteration is deterministic in that state, so every point goes through exactly the
+// operations it went through before: bit for bit the same weights (tests/test_gpu_parity.py::test_lae_bit_exact).
+struct LaeCont {
+  int phase;            // 0: one pass (all 100 iterations); 1: first pass, park the unfinished; 2: continuation over the list
+  int t_cut;
+  int cap;              // capacity of the list (= n)
+  int *count;           // number of parked points
+  int *list;            // their indices
+  double *state;        // [2R + 1][cap]
+};
+
 template <int R, int DPL, int LP>
 __global__ __launch_bounds__(64) void lae_reg_kernel(const double *__restrict__ X, int n, int ldx, int d,
                                                      const double *__restrict__ Ut, int dpad,
                                                      const int *__restrict__ knn_idx, int ldk,
                                                      int *__restrict__ ell_idx, double *__restrict__ ell_val,
-                                                     LaeMomentum mom) {
+                                                     LaeMomentum mom, LaeCont ct) {
   constexpr int PTS = 64 / LP;
   constexpr int NG = R * (R + 1) / 2;
   __shared__ double Gl[NG * PTS];    // packed upper triangle of U_i U_i^T, [e][point]
@@ -58,8 +74,17 @@ __global__ __launch_bounds__(64) void lae_reg_kernel(const double *__restrict__ 
   const int sub = tid & (LP - 1), pl = tid / LP;
   const int kb = sub * DPL;
   long i = (long)blockIdx.x * PTS + pl;
-  const bool live = i < n;
-  if (!live) i = n - 1;
+  bool live = i < n;
+  long slot = 0;
+  if (ct.phase == 2) {
+    const int cnt = *ct.count;
+    if ((long)blockIdx.x * PTS >= cnt) return;          // (uniform: the whole wave)
+    slot = i;
+    live = slot < cnt;
+    if (!live) slot = cnt - 1;                           // idle lanes shadow the last parked point: no extra iterations
+    i = ct.list[slot];
+  }
+  if (!live && ct.phase != 2) i = n - 1;
   int id[R];
 #pragma unroll
   for (int a = 0; a < R; ++a) id[a] = knn_idx[(size_t)a * ldk + i];
@@ -145,7 +170,14 @@ __global__ __launch_bounds__(64) void lae_reg_kernel(const double *__restrict__ 
 #pragma unroll
   for (int a = 0; a < R; ++a) { zp[a] = z0; zc[a] = z0; }
   int be = 0;  // beta_curr = 2^be
-  for (int t = 0; t < 100; ++t) {
+  if (ct.phase == 2) {
+#pragma unroll
+    for (int a = 0; a < R; ++a) { zp[a] = ct.state[(size_t)a * ct.cap + slot]; zc[a] = ct.state[(size_t)(R + a) * ct.cap + slot]; }
+    be = (int)ct.state[(size_t)(2 * R) * ct.cap + slot];
+  }
+  const int t_begin = ct.phase == 2 ? ct.t_cut : 0, t_end = ct.phase == 1 ? ct.t_cut : 100;
+  bool done = false;
+  for (int t = t_begin; t < t_end; ++t) {
     const double alpha = mom.alpha[t];
 #pragma unroll
     for (int a = 0; a < R; ++a) v[a] = zc[a] + alpha * (zc[a] - zp[a]);
@@ -186,7 +218,25 @@ __global__ __launch_bounds__(64) void lae_reg_kernel(const double *__restrict__ 
       const double df = zc[a] - zp[a];
       sq = (a == 0) ? df * df : __builtin_fma(df, df, sq);
     }
-    if (sq < 1e-5) break;
+    if (sq < 1e-5) { done = true; break; }
+  }
+  if (ct.phase == 1) {
+    // park the points that are not done: one counter increment per wave, slots in lane order
+    const bool park = live && !done && sub == 0;
+    const unsigned long long mask = __ballot(park);
+    int base = 0;
+    if (mask) {
+      if (tid == (int)__builtin_ctzll(mask)) base = atomicAdd(ct.count, (int)__builtin_popcountll(mask));
+      base = __shfl(base, (int)__builtin_ctzll(mask), 64);
+    }
+    if (park) {
+      const long sl = base + (long)__builtin_popcountll(mask & ((1ull << tid) - 1ull));
+      ct.list[sl] = (int)i;
+#pragma unroll
+      for (int a = 0; a < R; ++a) { ct.state[(size_t)a * ct.cap + sl] = zp[a]; ct.state[(size_t)(R + a) * ct.cap + sl] = zc[a]; }
+      ct.state[(size_t)(2 * R) * ct.cap + sl] = (double)be;
+    }
+    if (!done) live = false;       // its row is written by the second pass
   }
   // ELL row sorted by anchor index (what the CSR conversion of the reference produces)
   int key[R];
@@ -218,9 +268,25 @@ __global__ __launch_bounds__(64) void lae_reg_kernel(const double *__restrict__ 
 template <int R, int DPL, int LP>
 int launch_lae_reg_t(FLGP_LAE_REG_ARGS) {
   ProfScope ps("lae_kernel", st, 8.0 * (double)n * R);
+  const int t_cut = tuning("lae_cut", 13);   // (C3: one pass 2.62 ms; cut 8 / 10 / 12 / 14 / 16 / 18: 2.82 / 2.58 / 2.44 / 2.43 / 2.54 / 2.60)
+  if (t_cut <= 0 || t_cut >= 100 || n < tuning("lae_cut_min_n", 32768)) {
+    hipLaunchKernelGGL((lae_reg_kernel<R, DPL, LP>), dim3(ceil_div(n, 64 / LP)), dim3(64), 0, st, dX, n, ldx, d, dUt,
+                       dpad, d_knn, ldk, d_ei, d_ev, lae_momentum(), LaeCont{0, 0, 0, nullptr, nullptr, nullptr});
+    return check_launch("lae_reg_kernel");
+  }
+  // two passes with the unfinished points compacted in between (see LaeCont)
+  DevBuf list, state;
+  FLGP_TRY(list.alloc(sizeof(int) * ((size_t)n + 64)));
+  FLGP_TRY(state.alloc(sizeof(double) * (size_t)n * (2 * R + 1)));
+  int *count = list.as<int>() + n;          // (the counter lives behind the list)
+  FLGP_HIP(hipMemsetAsync(count, 0, sizeof(int), st));
+  LaeCont ct{1, t_cut, n, count, list.as<int>(), state.as<double>()};
   hipLaunchKernelGGL((lae_reg_kernel<R, DPL, LP>), dim3(ceil_div(n, 64 / LP)), dim3(64), 0, st, dX, n, ldx, d, dUt,
-                     dpad, d_knn, ldk, d_ei, d_ev, lae_momentum());
-  return check_launch("lae_reg_kernel");
+                     dpad, d_knn, ldk, d_ei, d_ev, lae_momentum(), ct);
+  ct.phase = 2;
+  hipLaunchKernelGGL((lae_reg_kernel<R, DPL, LP>), dim3(ceil_div(n, 64 / LP)), dim3(64), 0, st, dX, n, ldx, d, dUt,
+                     dpad, d_knn, ldk, d_ei, d_ev, lae_momentum(), ct);
+  return check_launch("lae_reg_kernel");     // (list / state go back to the cache: that synchronises the device)
 }
 
 #define FLGP_LAE_REG_PASS st, dX, n, ldx, d, dUt, dpad, d_knn, ldk, d_ei, d_ev

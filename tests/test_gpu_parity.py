@@ -259,6 +259,19 @@ def test_lae_bit_exact(oracle, r, d):
     np.testing.assert_array_equal(Z.indices.reshape(n, r), ei)
     np.testing.assert_array_equal(Z.data.reshape(n, r), ev)      # bit for bit
     assert (ev >= 0).all() and np.abs(ev.sum(1) - 1).max() < 1e-13
+    # the same through the two-pass form of the register kernels (iteration budget + compaction of the unfinished points,
+    # csrc/lae_reg.h): forced on at this size, with cuts that park almost every point, about half of them, and hardly any
+    L = _lib.lib()
+    L.flgp_set_tuning(b"lae_cut_min_n", 0)
+    try:
+        for cut in (1, 7, 40):
+            L.flgp_set_tuning(b"lae_cut", cut)
+            Z2 = api.LAE_cpp(X, U0, r)
+            np.testing.assert_array_equal(Z2.indices.reshape(n, r), ei)
+            np.testing.assert_array_equal(Z2.data.reshape(n, r), ev)
+    finally:
+        L.flgp_set_tuning(b"lae_cut_min_n", 32768)
+        L.flgp_set_tuning(b"lae_cut", 13)
 
 
 def test_lae_huge_coordinates(oracle):
