@@ -52,6 +52,7 @@ _SIGNATURES = {
     "flgp_eigenpair_vty": (c_int, [P, c_int, P, c_int, P, c_int, P]),
     "flgp_eigenpair_vc": (c_int, [P, c_int, P, c_int, P, c_int, P]),
     "flgp_eigenpair_predict_regression": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, c_double, c_double, c_double, P]),
+    "flgp_eigenpair_predict_regression_different": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, c_double, P, c_double, P]),
     "flgp_eigenpair_posterior_variance": (c_int, [P, c_int, P, c_int, P, c_int, c_double, c_double, c_double, P]),
     "flgp_eigenpair_free": (None, [P]),
     "flgp_kmeans_lloyd": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, P, P, P]),

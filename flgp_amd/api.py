@@ -226,12 +226,20 @@ class ResidentEigenPair:
 
     def predict_regression_cpp(self, Y, idx0, idx1, K, pars, sigma, noisepar="same"):
         """predict_regression_cpp (src/Predict.cpp:40-75) on the resident pair: Y (m x q) goes up, Y_pred (m_new x q)
-        comes down; the Woodbury / Cholesky algebra runs on the device.  ``pars = (t, noise)``."""
-        if noisepar != "same":
-            raise FlgpError(-3, 'predict_regression_cpp: only noisepar="same" is built on the device')
+        comes down; the Woodbury / Cholesky algebra runs on the device.  ``pars = (t, noise)`` for noisepar = "same",
+        ``(t, noise_1, ..., noise_m)`` for "different" (src/Predict.cpp:76-110)."""
         idx0 = np.ascontiguousarray(idx0, dtype=np.int32); idx1 = np.ascontiguousarray(idx1, dtype=np.int32)
         Y = np.asfortranarray(np.asarray(Y, dtype=np.float64).reshape(idx0.size, -1))
         out = np.zeros((idx1.size, Y.shape[1]), order="F")
+        if noisepar == "different":
+            nz = np.ascontiguousarray(np.asarray(pars[1:], dtype=np.float64))
+            if nz.size != idx0.size:
+                raise ValueError('noisepar="different" needs one noise variance per training row: pars = (t, noise_1 .. noise_m)')
+            check(_lib.lib().flgp_eigenpair_predict_regression_different(self._h, int(K), _ptr(idx0), idx0.size, _ptr(idx1), idx1.size,
+                                                                         _ptr(Y), Y.shape[1], float(pars[0]), _ptr(nz), float(sigma), _ptr(out)))
+            return out
+        if noisepar != "same":
+            raise FlgpError(-3, 'predict_regression_cpp: noisepar must be "same" or "different"')
         check(_lib.lib().flgp_eigenpair_predict_regression(self._h, int(K), _ptr(idx0), idx0.size, _ptr(idx1), idx1.size, _ptr(Y),
                                                            Y.shape[1], float(pars[0]), float(pars[1]), float(sigma), _ptr(out)))
         return out

@@ -920,6 +920,78 @@ extern "C" int flgp_eigenpair_predict_regression(const flgp_eigenpair *ep, int K
   return G.verdict(st.s, "predict_regression");
 }
 
+// predict_regression_cpp with noisepar = "different" (reference src/Predict.cpp:76-110): one noise variance per training
+// row, pars = (t, noise_1 .. noise_m).  m <= K: the m x m kernel matrix with sigma + noise_i on its diagonal.  m > K: with
+// Z^-1 = diag(1 / (noise_i + sigma)),  Q = Ls V^T Z^-1 V Ls + I,  alpha = Z^-1 Y - Z^-1 V Ls Q^-1 Ls V^T Z^-1 Y; only
+// V^T alpha = V^T Z^-1 Y - (V^T Z^-1 V) Ls Q^-1 Ls V^T Z^-1 Y is formed (K x q), never the m x q alpha.
+extern "C" int flgp_eigenpair_predict_regression_different(const flgp_eigenpair *ep, int K, const int *idx0, int m,
+                                                           const int *idx1, int mnew, const double *Y, int q, double t,
+                                                           const double *noise, double sigma, double *Y_pred) {
+  FLGP_REQUIRE(ep && idx0 && idx1 && Y && Y_pred && noise, "predict_regression: null pointer");
+  FLGP_REQUIRE(K >= 1 && K <= ep->K && m >= 1 && mnew >= 1 && q >= 1, "predict_regression: bad shape (K=%d m=%d m_new=%d q=%d)", K, m, mnew, q);
+  for (int a = 0; a < m; ++a) FLGP_REQUIRE(noise[a] + sigma > 0.0, "predict_regression: noise[%d] + sigma must be positive", a);
+  for (int a = 0; a < m; ++a) FLGP_REQUIRE(idx0[a] >= 0 && idx0[a] < ep->n, "predict_regression: idx0[%d]=%d out of range", a, idx0[a]);
+  for (int a = 0; a < mnew; ++a) FLGP_REQUIRE(idx1[a] >= 0 && idx1[a] < ep->n, "predict_regression: idx1[%d]=%d out of range", a, idx1[a]);
+  Stream st;
+  FLGP_TRY(st.create());
+  GprCtx G;
+  FLGP_TRY(G.prepare(st.s, ep, K, t));
+  const double *dval = (const double *)ep->values.p, *dvec = (const double *)ep->vectors.p;
+  DevBuf dY, out, dnoise;
+  FLGP_TRY(dY.alloc(sizeof(double) * (size_t)m * q));
+  FLGP_TRY(out.alloc(sizeof(double) * (size_t)mnew * q));
+  FLGP_TRY(dnoise.alloc(sizeof(double) * (size_t)m));
+  FLGP_TRY(h2d(dY.p, Y, sizeof(double) * (size_t)m * q, st.s));
+  FLGP_TRY(h2d(dnoise.p, noise, sizeof(double) * (size_t)m, st.s));
+  if (m <= K) {
+    // Cvv + sigma I + diag(noise), Cholesky, alpha = C^-1 Y, Y_pred = Cnv alpha       (src/Predict.cpp:78-91)
+    DevBuf i0, i1, C, Cnv, work;
+    const int *d0, *d1; int r0, r1;
+    FLGP_TRY(upload_idx(st.s, idx0, m, i0, &d0, &r0));
+    FLGP_TRY(upload_idx(st.s, idx1, mnew, i1, &d1, &r1));
+    FLGP_TRY(C.alloc(sizeof(double) * (size_t)m * m));
+    FLGP_TRY(Cnv.alloc(sizeof(double) * (size_t)mnew * m));
+    FLGP_TRY(work.alloc(flgp_dev_hk_workspace(std::max(m, mnew), m, K, 1)));
+    FLGP_TRY(flgp_dev_hk(st.s, dval, K, t, dvec, ep->n, d0, r0, m, dvec, ep->n, d0, r0, m, C.as<double>(), m, work.as<double>()));
+    FLGP_TRY(gpr_add_diag(st.s, C.as<double>(), m, sigma));
+    FLGP_TRY(gpr_add_diag_vec(st.s, C.as<double>(), m, dnoise.as<double>()));
+    FLGP_TRY(flgp_dev_hk(st.s, dval, K, t, dvec, ep->n, d1, r1, mnew, dvec, ep->n, d0, r0, m, Cnv.as<double>(), mnew, work.as<double>()));
+    FLGP_TRY(chol_solve(st.s, C.as<double>(), m, dY.as<double>(), q, G.flag.as<int>()));
+    FLGP_TRY(gemm_launch(st.s, mnew, q, m, 1.0, Cnv.as<double>(), 1, mnew, dY.as<double>(), 1, m, 0.0, nullptr, 0, 0,
+                         out.as<double>(), 1, mnew, nullptr, 0, 0.0, nullptr));
+  } else {
+    GatheredV g0, g1;
+    FLGP_TRY(gather_v(st.s, ep, K, idx0, m, g0));
+    FLGP_TRY(gather_v(st.s, ep, K, idx1, mnew, g1));
+    DevBuf zinv, ZV, ZY, VtZV, VtZY, Q, R, T1, work;
+    const size_t we = (size_t)128 * K * K + (size_t)64 * K * q + 1024;
+    FLGP_TRY(zinv.alloc(sizeof(double) * (size_t)m));
+    FLGP_TRY(ZV.alloc(sizeof(double) * (size_t)m * K)); FLGP_TRY(ZY.alloc(sizeof(double) * (size_t)m * q));
+    FLGP_TRY(VtZV.alloc(sizeof(double) * (size_t)K * K)); FLGP_TRY(Q.alloc(sizeof(double) * (size_t)K * K));
+    FLGP_TRY(VtZY.alloc(sizeof(double) * (size_t)K * q)); FLGP_TRY(R.alloc(sizeof(double) * (size_t)K * q));
+    FLGP_TRY(T1.alloc(sizeof(double) * (size_t)K * q)); FLGP_TRY(work.alloc(sizeof(double) * we));
+    FLGP_TRY(gpr_zinv(st.s, dnoise.as<double>(), sigma, m, zinv.as<double>()));                                  // :98-101
+    FLGP_TRY(gpr_rowscale_ld(st.s, g0.V, g0.ld, zinv.as<double>(), m, K, ZV.as<double>()));                     // Z^-1 V
+    FLGP_TRY(gpr_rowscale_ld(st.s, dY.as<double>(), m, zinv.as<double>(), m, q, ZY.as<double>()));              // Z^-1 Y
+    FLGP_TRY(gemm_launch(st.s, K, K, m, 1.0, g0.V, g0.ld, 1, ZV.as<double>(), 1, m, 0.0, nullptr, 0, 0, VtZV.as<double>(), 1, K,
+                         work.as<double>(), we, 0.0, nullptr));                                                 // V^T Z^-1 V   :102
+    FLGP_TRY(gemm_launch(st.s, K, q, m, 1.0, g0.V, g0.ld, 1, ZY.as<double>(), 1, m, 0.0, nullptr, 0, 0, VtZY.as<double>(), 1, K,
+                         work.as<double>(), we, 0.0, nullptr));                                                 // V^T Z^-1 Y
+    FLGP_TRY(gpr_q(st.s, VtZV.as<double>(), G.ls.as<double>(), K, 1.0, Q.as<double>()));                        // :103-104
+    FLGP_TRY(gpr_scale(st.s, VtZY.as<double>(), G.ls.as<double>(), nullptr, K, q, R.as<double>()));
+    FLGP_TRY(chol_solve(st.s, Q.as<double>(), K, R.as<double>(), q, G.flag.as<int>()));                         // :105-106
+    FLGP_TRY(gpr_scale(st.s, R.as<double>(), G.ls.as<double>(), nullptr, K, q, R.as<double>()));
+    FLGP_TRY(gemm_launch(st.s, K, q, K, 1.0, VtZV.as<double>(), 1, K, R.as<double>(), 1, K, 0.0, nullptr, 0, 0, T1.as<double>(), 1, K,
+                         nullptr, 0, 0.0, nullptr));
+    FLGP_TRY(gpr_diff(st.s, VtZY.as<double>(), T1.as<double>(), 1.0, (long)K * q, T1.as<double>()));            // V^T alpha
+    FLGP_TRY(gpr_scale(st.s, T1.as<double>(), G.l.as<double>(), nullptr, K, q, T1.as<double>()));               // exp(-t lam) (.)
+    FLGP_TRY(gemm_launch(st.s, mnew, q, K, 1.0, g1.V, 1, g1.ld, T1.as<double>(), 1, K, 0.0, nullptr, 0, 0, out.as<double>(), 1,
+                         mnew, nullptr, 0, 0.0, nullptr));                                                      // :108-109
+  }
+  FLGP_TRY(d2h(Y_pred, out.p, sizeof(double) * (size_t)mnew * q, st.s));
+  return G.verdict(st.s, "predict_regression");
+}
+
 extern "C" int flgp_eigenpair_posterior_variance(const flgp_eigenpair *ep, int K, const int *idx0, int m, const int *idx1,
                                                  int mnew, double t, double var, double sigma, double *cov) {
   FLGP_REQUIRE(ep && idx0 && idx1 && cov, "posterior_variance: null pointer");

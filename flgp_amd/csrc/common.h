@@ -124,6 +124,9 @@ int gpr_q(hipStream_t st, const double *dVtV, const double *d_ls, int K, double 
 int gpr_scale(hipStream_t st, const double *dM, const double *d_a, const double *d_b, int rows, int cols, double *d_out);
 int gpr_diff(hipStream_t st, const double *dX, const double *dY, double alpha, long count, double *d_out);
 int gpr_add_diag(hipStream_t st, double *dA, int N, double c);
+int gpr_add_diag_vec(hipStream_t st, double *dA, int N, const double *d_v);
+int gpr_rowscale_ld(hipStream_t st, const double *dM, long ldm, const double *d_a, int rows, int cols, double *d_out);
+int gpr_zinv(hipStream_t st, const double *d_noise, double sigma, int m, double *d_zinv);
 int gpr_rowquad(hipStream_t st, const double *dV2, long ld2, const double *dW, int mnew, int K, const double *d_l, double c,
                 double *d_cov);
 int gpr_rowdot(hipStream_t st, const double *dC21, const double *dAl, int mnew, int m, const double *dV2, long ld2, int K,

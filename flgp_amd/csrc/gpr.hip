@@ -111,6 +111,24 @@ __global__ void gpr_add_diag_kernel(double *__restrict__ A, int N, double c) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < N) A[(size_t)i * N + i] += c;
 }
+// A(i, i) += v[i]
+__global__ void gpr_add_diag_vec_kernel(double *__restrict__ A, int N, const double *__restrict__ v) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) A[(size_t)i * N + i] += v[i];
+}
+// out(i, j) = a(i) * M(i, j): M rows x cols with leading dimension ldm, out contiguous (rows x cols)
+__global__ void gpr_rowscale_ld_kernel(const double *__restrict__ M, long ldm, const double *__restrict__ a, int rows, int cols,
+                                       double *__restrict__ out) {
+  const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long)rows * cols) return;
+  const int i = (int)(e % rows), j = (int)(e / rows);
+  out[e] = a[i] * M[(size_t)j * ldm + i];
+}
+// zinv[i] = 1 / (noise[i] + sigma)
+__global__ void gpr_zinv_kernel(const double *__restrict__ noise, double sigma, int m, double *__restrict__ zinv) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) zinv[i] = 1.0 / (noise[i] + sigma);
+}
 
 // cov_i = sum_k V2(i,k)^2 l_k + c - sum_k V2(i,k) W(i,k)            (src/Utils.cpp:249: rowwise sums, k ascending)
 __global__ void gpr_rowquad_kernel(const double *__restrict__ V2, long ld2, const double *__restrict__ W, int mnew, int K,
@@ -158,6 +176,18 @@ int gpr_diff(hipStream_t st, const double *dX, const double *dY, double alpha, l
 int gpr_add_diag(hipStream_t st, double *dA, int N, double c) {
   hipLaunchKernelGGL(gpr_add_diag_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, dA, N, c);
   return check_launch("gpr_add_diag_kernel");
+}
+int gpr_add_diag_vec(hipStream_t st, double *dA, int N, const double *d_v) {
+  hipLaunchKernelGGL(gpr_add_diag_vec_kernel, dim3(ceil_div(N, 256)), dim3(256), 0, st, dA, N, d_v);
+  return check_launch("gpr_add_diag_vec_kernel");
+}
+int gpr_rowscale_ld(hipStream_t st, const double *dM, long ldm, const double *d_a, int rows, int cols, double *d_out) {
+  hipLaunchKernelGGL(gpr_rowscale_ld_kernel, dim3(ceil_div((long)rows * cols, 256)), dim3(256), 0, st, dM, ldm, d_a, rows, cols, d_out);
+  return check_launch("gpr_rowscale_ld_kernel");
+}
+int gpr_zinv(hipStream_t st, const double *d_noise, double sigma, int m, double *d_zinv) {
+  hipLaunchKernelGGL(gpr_zinv_kernel, dim3(ceil_div(m, 256)), dim3(256), 0, st, d_noise, sigma, m, d_zinv);
+  return check_launch("gpr_zinv_kernel");
 }
 int gpr_rowquad(hipStream_t st, const double *dV2, long ld2, const double *dW, int mnew, int K, const double *d_l, double c,
                 double *d_cov) {

@@ -45,7 +45,7 @@ struct Hk2Args {
   int nblocks;                            // panels: ceil(n0 / HP2)
 };
 
-template <int NST, int PG>
+template <int NST, int PG, int STORE_AUX>
 __global__ __launch_bounds__(512, 1) void hk_panel2_kernel(Hk2Args g) {
   constexpr int NKS = NST * 4;            // k steps per tile
   constexpr int NKP = NST * 2;            // k-step pairs = ring stages per tile
@@ -171,7 +171,7 @@ __global__ __launch_bounds__(512, 1) void hk_panel2_kernel(Hk2Args g) {
 #pragma unroll
             for (int ni = 0; ni < 4; ++ni) {
               const double v = acc[m][ni][reg];      // (a copy: __builtin_bit_cast of the vector element itself took element 0)
-              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ku2, v), h_rsrc, h_lane + (unsigned)(ni * 128), row_off[m][reg], 0);
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ku2, v), h_rsrc, h_lane + (unsigned)(ni * 128), row_off[m][reg], STORE_AUX);
             }
           }
       } else {
@@ -185,7 +185,7 @@ __global__ __launch_bounds__(512, 1) void hk_panel2_kernel(Hk2Args g) {
             for (int ni = 0; ni < 4; ++ni)
               if (a0 + ni * 16 < (long)g.n0 && b < g.n1) {
                 const double v = acc[m][ni][reg];
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ku2, v), h_rsrc, h_lane + (unsigned)(ni * 128), row_off[m][reg], 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(ku2, v), h_rsrc, h_lane + (unsigned)(ni * 128), row_off[m][reg], STORE_AUX);
               }
           }
       }
@@ -268,8 +268,11 @@ int hk_panel2_launch(hipStream_t st, const double *d_values, int K, double t, co
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(512), lds, st, g);
     return FLGP_OK;
   };
-  if (nst == 13) FLGP_TRY(go(hk_panel2_kernel<13, 7>));
-  else FLGP_TRY(go(hk_panel2_kernel<7, 4>));
+  // H is written once and not read again on the device: non-temporal stores (aux bit 1) keep it from pushing the
+  // L2-resident small operand and the next panels out of the caches (knob hk_store_nt, default on: see DESIGN.md)
+  const bool nt = tuning("hk_store_nt", 1) != 0;
+  if (nst == 13) { if (nt) FLGP_TRY(go(hk_panel2_kernel<13, 7, 2>)); else FLGP_TRY(go(hk_panel2_kernel<13, 7, 0>)); }
+  else { if (nt) FLGP_TRY(go(hk_panel2_kernel<7, 4, 2>)); else FLGP_TRY(go(hk_panel2_kernel<7, 4, 0>)); }
   return check_launch("hk_panel2_kernel");
 }
 

@@ -456,6 +456,35 @@ def np_predict_regression(values, vectors, Y, idx0, idx1, K, pars, sigma):
     return Vnv @ ((np.exp(-t * lam) + 0.0)[:, None] * (V.T @ alpha))               # :72
 
 
+def np_predict_regression_different(values, vectors, Y, idx0, idx1, K, pars, sigma):
+    """predict_regression_cpp with noisepar = "different" (reference src/Predict.cpp:76-110), line by line in numpy:
+    ``pars = (t, noise_1, ..., noise_m)``, one noise variance per training row."""
+    import scipy.linalg as sl
+    values = np.asarray(values, dtype=np.float64); vectors = np.asarray(vectors, dtype=np.float64)
+    Y = np.asarray(Y, dtype=np.float64).reshape(len(idx0), -1)
+    t = float(pars[0]); nz = np.asarray(pars[1:], dtype=np.float64)
+    m = Y.shape[0]
+    if m <= K:
+        C_noisy = np_hk(values, vectors, K, t, idx0, idx0)                          # :79
+        C_noisy[np.diag_indices(m)] += sigma                                       # :81
+        C_noisy[np.diag_indices(m)] += nz                                          # :82-84
+        Cnv = np_hk(values, vectors, K, t, idx1, idx0)                              # :85
+        alpha = sl.cho_solve(sl.cho_factor(C_noisy, lower=True), Y)                 # :88-89
+        return Cnv @ alpha                                                         # :90
+    lam = 1.0 - values[:K]                                                         # :93
+    V = vectors[idx0, :K]                                                          # :97
+    ls = np.exp(-0.5 * t * lam) + 0.0                                              # :98
+    zinv = 1.0 / (nz + sigma)                                                      # :99-102
+    VtZV = V.T @ (zinv[:, None] * V)                                               # :103
+    Q = (ls[:, None] * VtZV) * ls[None, :]                                         # :104
+    Q[np.diag_indices(K)] += 1.0                                                   # :105
+    ZY = zinv[:, None] * Y
+    x = sl.cho_solve(sl.cho_factor(Q, lower=True), ls[:, None] * (V.T @ ZY))       # :106-107
+    alpha = ZY - zinv[:, None] * ((V * ls[None, :]) @ x)                           # :107
+    Vnv = vectors[idx1, :K]                                                        # :109
+    return Vnv @ ((np.exp(-t * lam) + 0.0)[:, None] * (V.T @ alpha))               # :110
+
+
 def np_posterior_covariance_regression(values, vectors, idx0, idx1, K, pars, sigma):
     """posterior_covariance_regression (reference src/Utils.cpp:214-250) in numpy: ``pars = (t, var)``; returns the
     posterior variance of the rows idx1 (m_new,)."""

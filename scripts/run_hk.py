@@ -21,8 +21,18 @@ V = torch.randn((K, n0), dtype=torch.float64, device="cuda", generator=g)
 vals = torch.linspace(1.0, 0.4, K, dtype=torch.float64, device="cuda")
 V1 = V[:, :n1].contiguous()
 H = S.hk(vals, 10.0, V, V1); torch.cuda.synchronize()
+trash = None
+if os.environ.get("HK_TRASH"):
+    # what runs between two contractions in bench.py, roughly: other kernels over other memory (cold TLBs / caches, another clock state)
+    trash = torch.empty(int(float(os.environ["HK_TRASH"]) * (1 << 30) // 8), dtype=torch.float64, device="cuda")
+    A = torch.randn((4096, 4096), dtype=torch.float64, device="cuda", generator=g)
 ts = []
 for _ in range(reps):
+    if trash is not None:
+        trash.add_(1.0)
+        if os.environ.get("HK_TRASH_MM"):
+            for _q in range(int(os.environ["HK_TRASH_MM"])): B_ = A @ A
+        torch.cuda.synchronize()
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     e0.record(); H = S.hk(vals, 10.0, V, V1); e1.record(); torch.cuda.synchronize()
     ts.append(e0.elapsed_time(e1))

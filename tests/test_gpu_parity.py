@@ -749,6 +749,17 @@ def test_resident_regression_prediction_and_posterior_variance(oracle, m, K, q):
             prior = ((ep.vectors[idx1, :K] ** 2) * np.exp(-t * (1.0 - ep.values[:K]))).sum(1).max()
             np.testing.assert_allclose(gotv, refv, rtol=0, atol=1e-9 * np.abs(refv).max() + 2e-15 * prior * m / (noise + sigma))
             assert (gotv > 0).all()
+    # noisepar = "different" (src/Predict.cpp:76-110): one noise variance per training row
+    for idx0, idx1 in [(np.arange(m), np.arange(m, n)), (rng.permutation(n)[:m], rng.permutation(n)[:500])]:
+        nz = rng.uniform(0.01, 0.5, m)
+        pars = np.concatenate([[6.0], nz])
+        ref = oracle.np_predict_regression_different(ep.values, ep.vectors, Y, idx0, idx1, K, pars, sigma)
+        got = rp.predict_regression_cpp(Y, idx0, idx1, K, pars, sigma, noisepar="different")
+        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-9 * np.abs(ref).max())
+    # ... and with equal variances it is the "same" model
+    same = rp.predict_regression_cpp(Y, np.arange(m), np.arange(m, n), K, (6.0, 0.2), sigma)
+    diff = rp.predict_regression_cpp(Y, np.arange(m), np.arange(m, n), K, np.concatenate([[6.0], np.full(m, 0.2)]), sigma, noisepar="different")
+    np.testing.assert_allclose(diff, same, rtol=0, atol=1e-9 * np.abs(same).max())
     with pytest.raises(api.FlgpError):
         rp.predict_regression_cpp(Y, np.arange(m), np.array([n]), K, (1.0, 0.1), sigma)          # row out of range
     with pytest.raises(api.FlgpError):

@@ -200,3 +200,26 @@ def test_golden_fixtures(oracle, path):
     np.testing.assert_array_equal(zn, g["z_val"])
     H = oracle.heat_kernel_covariance(X[:m], X[m:], U, r, t, K=K, gl=gl, root=root)
     assert np.abs(H - g["H"]).max() <= 1e-9 * np.abs(g["H"]).max()
+
+
+def test_predict_regression_different_reduces_to_same(oracle):
+    O = oracle
+    """The numpy restatement of predict_regression_cpp's noisepar = "different" branch (src/Predict.cpp:76-110) with equal
+    noise variances is the "same" branch (:46-75) -- both sides of m <= K."""
+    rng = np.random.default_rng(3)
+    n, Kt = 400, 30
+    vec = np.asfortranarray(np.linalg.qr(rng.normal(size=(n, Kt)))[0] * np.sqrt(n))
+    vals = np.sort(rng.uniform(0.2, 1.0, Kt))[::-1].copy()
+    for m, K in [(20, 30), (120, 25)]:
+        idx0 = rng.permutation(n)[:m]; idx1 = rng.permutation(n)[:77]
+        Y = rng.normal(size=(m, 2))
+        same = O.np_predict_regression(vals, vec, Y, idx0, idx1, K, (3.0, 0.3), 1e-3)
+        diff = O.np_predict_regression_different(vals, vec, Y, idx0, idx1, K, np.concatenate([[3.0], np.full(m, 0.3)]), 1e-3)
+        np.testing.assert_allclose(diff, same, rtol=0, atol=1e-10 * np.abs(same).max())
+        # unequal variances: a row with a huge variance is ignored by the fit -- same prediction as without the row
+        nz = np.full(m, 0.3); nz[0] = 1e12
+        with_row = O.np_predict_regression_different(vals, vec, Y, idx0, idx1, K, np.concatenate([[3.0], nz]), 1e-3)
+        without = O.np_predict_regression_different(vals, vec, Y[1:], idx0[1:], idx1, min(K, m - 1) if m <= K else K,
+                                                    np.concatenate([[3.0], nz[1:]]), 1e-3) if m > K else None
+        if without is not None:
+            np.testing.assert_allclose(with_row, without, rtol=0, atol=1e-6 * np.abs(without).max())
