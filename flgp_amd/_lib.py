@@ -55,6 +55,7 @@ _SIGNATURES = {
     "flgp_eigenpair_predict_regression_different": (c_int, [P, c_int, P, c_int, P, c_int, P, c_int, c_double, P, c_double, P]),
     "flgp_eigenpair_posterior_variance": (c_int, [P, c_int, P, c_int, P, c_int, c_double, c_double, c_double, P]),
     "flgp_eigenpair_free": (None, [P]),
+    "flgp_kmeans_minibatch": (c_int, [P, c_int, c_int, c_int, c_int, c_int, c_int, c_double, c_int, ctypes.c_ulonglong, P, P, P]),
     "flgp_kmeans_lloyd": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, P, P, P]),
     "flgp_nystrom_eigenpair": (c_int, [P, c_int, c_int, P, c_int, c_double, c_int, P, P]),
     "flgp_nystrom_eigenpair_resident": (c_int, [P, c_int, c_int, P, c_int, c_double, c_int, P]),

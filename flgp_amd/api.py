@@ -315,6 +315,19 @@ def kmeans_lloyd(X, s, init_rows, iter_max=100):
     return U, it.value, wss.value
 
 
+def kmeans_minibatch(X, s, batch_size=-1, num_init=1, max_iters=100, init_fraction=-1.0, early_stop_iter=10, seed=0):
+    """Mini-batch k-means on the device (include/flgp_hip.h ``flgp_kmeans_minibatch``).  Defaults = what the reference
+    passes to ClusterR::MiniBatchKmeans (src/Utils.cpp:52-55: batch_size = 10 s, init_fraction = 20 s / n; the rest at
+    ClusterR's defaults).  Returns (U (s x (d+1), sizes last), (iterations, winning start), tot_withinss)."""
+    X = _f64(X, "X")
+    n, d = X.shape
+    U = np.zeros((int(s), d + 1), order="F")
+    info = (ctypes.c_int * 2)(); wss = ctypes.c_double()
+    check(_lib.lib().flgp_kmeans_minibatch(_ptr(X), n, d, int(s), int(batch_size), int(num_init), int(max_iters), float(init_fraction),
+                                           int(early_stop_iter), int(seed), _ptr(U), ctypes.addressof(info), ctypes.byref(wss)))
+    return U, (info[0], info[1]), wss.value
+
+
 def subsample_cpp(X, s, method="kmeans", nstart=1, rng=None):
     """subsample_cpp (src/Utils.cpp:32-68).  ``"random"``: rows drawn without replacement (a numpy Generator in place
     of R's ``sample``).  ``"lloyd"``: k-means on the device from ``nstart`` random starts, iter.max = 100 -- same output
@@ -329,10 +342,14 @@ def subsample_cpp(X, s, method="kmeans", nstart=1, rng=None):
     if method == "lloyd":
         rows = np.stack([rng.choice(X.shape[0], size=int(s), replace=False) for _ in range(max(1, int(nstart)))])
         return kmeans_lloyd(X, s, rows, iter_max=100)[0]
+    if method == "minibatch":
+        # the algorithm and parameters of the reference's "minibatchkmeans" branch (src/Utils.cpp:49-56), on the device and
+        # on this library's RNG (ClusterR draws from R's: same distribution, other values)
+        return kmeans_minibatch(X, s, num_init=max(1, int(nstart)), seed=int(rng.integers(0, 2**62)))[0]
     if method in ("kmeans", "minibatchkmeans"):
         raise NotImplementedError(
             f"subsample=\"{method}\" is R's stats::kmeans / ClusterR (outside the accelerated path): "
-            "compute the anchors there and pass them as U (s x (d+1), cluster sizes last), or use subsample=\"lloyd\"")
+            "compute the anchors there and pass them as U (s x (d+1), cluster sizes last), or use subsample=\"lloyd\" / \"minibatch\"")
     raise FlgpError(-3, "The subsample method is not supported!")
 
 

@@ -150,6 +150,16 @@ static SEXP subsample(SEXP X, int s, const char *method, int nstart) {
     UNPROTECT(1);
     return U;
   }
+  if (strcmp(method, "minibatch") == 0) {
+    /* extension: the algorithm and arguments of the "minibatchkmeans" branch above (src/Utils.cpp:49-62) on
+     * the device instead of through ClusterR; the seed is drawn from R's RNG (the caller holds GetRNGstate) */
+    if (nstart < 1) nstart = 1;
+    const unsigned long long seed = (unsigned long long)(unif_rand() * 9007199254740992.0);
+    SEXP U = PROTECT(Rf_allocMatrix(REALSXP, s, d + 1));
+    chk(flgp_kmeans_minibatch(REAL(X), n, d, s, -1, nstart, 100, -1.0, 10, seed, REAL(U), NULL, NULL));
+    UNPROTECT(1);
+    return U;
+  }
   Rf_error("The subsample method is not supported!"); /* src/Utils.cpp:64 */
   return R_NilValue;
 }

@@ -571,3 +571,137 @@ def np_kmeans_lloyd(X, init_rows, iter_max=100):
         if it >= iter_max:
             break
     return np.asfortranarray(np.hstack([C, size[:, None]])), it
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Mini-batch k-means: the algorithm behind subsample_cpp's "minibatchkmeans" branch.
+# The reference (src/Utils.cpp:49-62) calls ClusterR::MiniBatchKmeans(data = X, clusters = s, batch_size = 10 s,
+# init_fraction = 20 s / n, num_init = nstart) -- a third-party R package, version unpinned in DESCRIPTION, not under
+# /root/reference; its other arguments stay at their defaults: max_iters = 100, initializer = "kmeans++",
+# early_stop_iter = 10 -- and then counts 1-NN assignments (KNN_cpp(X, centres, 1)).  ClusterR draws from R's RNG, so this
+# restates the PUBLISHED algorithm (k-means++: Arthur & Vassilvitskii 2007; mini-batch updates: Sculley 2010) with those
+# parameters on the repo's seeded counter RNG, operation for operation as flgp_amd/csrc/minibatch.hip runs it.  Parity
+# unpinned like the rest of the oracle.
+_M64 = (1 << 64) - 1
+
+
+def _mb_mix(z):
+    z = (z + 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def _mb_uniform(seed, st, q):
+    h = _mb_mix((_mb_mix((seed + 0x632BE59BD9B4E019 * (st + 1)) & _M64) + q) & _M64)
+    return float(h >> 11) * (1.0 / 9007199254740992.0)
+
+
+def np_kmeans_minibatch(X, s, batch_size=-1, num_init=1, max_iters=100, init_fraction=-1.0, early_stop_iter=10, seed=0):
+    """Returns (U (s x (d+1): centres, then 1-NN sizes over all rows), info = (iterations, winning start), tot_withinss).
+    batch_size <= 0: the reference's 10 s; init_fraction <= 0: the reference's 20 s / n (src/Utils.cpp:53-54)."""
+    X = _f64(X)
+    n, d = X.shape
+    if batch_size <= 0:
+        batch_size = min(n, 10 * s)
+    if init_fraction <= 0:
+        init_fraction = min(1.0, 20.0 * s / n)
+    B = batch_size
+    nsub = min(n, max(s, int(np.ceil(init_fraction * n))))
+    nblk = (nsub + 1023) // 1024
+
+    def two_level(v):                                             # blocks of 1024 left to right, then the block sums left to right
+        bs = []
+        for b in range((len(v) + 1023) // 1024):
+            acc = 0.0
+            for x in v[b * 1024:(b + 1) * 1024]:
+                acc = acc + x
+            bs.append(acc)
+        return bs
+
+    best = None
+    for q in range(num_init):
+        base = 4 * q
+        perm = np.arange(n)
+        for i in range(nsub):
+            j = min(n - 1, i + int(_mb_uniform(seed, base + 0, i) * float(n - i)))
+            perm[i], perm[j] = perm[j], perm[i]
+        sub = perm[:nsub].copy()
+        Xs = X[sub]                                               # (nsub, d)
+
+        def dist2(c):                                             # coordinates ascending, multiply then add
+            acc = np.zeros(nsub)
+            for k in range(d):
+                df = Xs[:, k] - c[k]
+                acc = acc + df * df
+            return acc
+
+        C = np.zeros((s, d))
+        first = min(nsub - 1, int(_mb_uniform(seed, base + 1, 0) * float(nsub)))
+        C[0] = Xs[first]
+        d2 = None
+        for c in range(1, s):
+            v = dist2(C[c - 1])
+            d2 = v if d2 is None else np.where(v < d2, v, d2)
+            bsum = two_level(d2)
+            total = 0.0
+            for b in range(nblk):
+                total = total + bsum[b]
+            target = _mb_uniform(seed, base + 1, c) * total
+            acc = 0.0; blk = -1
+            for b in range(nblk):
+                nx = acc + bsum[b]
+                if nx > target:
+                    blk = b
+                    break
+                acc = nx
+            if blk < 0:
+                blk = nblk - 1
+                acc = 0.0
+                for b in range(blk):
+                    acc = acc + bsum[b]
+            i0, i1 = blk * 1024, min(blk * 1024 + 1024, nsub)
+            pick = i1 - 1
+            for qq in range(i0, i1):
+                acc = acc + d2[qq]
+                if acc > target:
+                    pick = qq
+                    break
+            C[c] = Xs[pick]
+        # mini-batch iterations: the batch is the head of the running permutation after B more Fisher-Yates draws
+        cnt = np.zeros(s)
+        draw = 0
+        best_sse = np.inf; stall = 0; iters = 0
+        for it in range(max_iters):
+            for p in range(B):
+                j = min(n - 1, p + int(_mb_uniform(seed, base + 2, draw) * float(n - p)))
+                draw += 1
+                perm[p], perm[j] = perm[j], perm[p]
+            batch = perm[:B].copy()
+            Xb = np.asfortranarray(X[batch])
+            lab, dist = knn(Xb, np.asfortranarray(C), 1, output=True)       # the centres as they stand at the start of the iteration
+            lab = lab[:, 0]; dist = dist[:, 0]
+            sse = 0.0
+            for x in two_level(dist):
+                sse = sse + x
+            for c in np.unique(lab):                              # per centre, its batch points in batch order
+                vv = cnt[c]; ck = C[c].copy()
+                for p in np.nonzero(lab == c)[0]:
+                    vv = vv + 1.0
+                    eta = 1.0 / vv
+                    ck = (1.0 - eta) * ck + eta * Xb[p]
+                cnt[c] = vv; C[c] = ck
+            iters = it + 1
+            if sse < best_sse:
+                best_sse = sse; stall = 0
+            else:
+                stall += 1
+            if stall >= early_stop_iter:
+                break
+        Cf = np.asfortranarray(C)
+        lab = knn(X, Cf, 1)[:, 0]
+        sizes = np.bincount(lab, minlength=s).astype(np.float64)
+        wss = float(((X - Cf[lab]) ** 2).sum())
+        if best is None or wss < best[2]:
+            best = (np.asfortranarray(np.hstack([Cf, sizes[:, None]])), (iters, q), wss)
+    return best

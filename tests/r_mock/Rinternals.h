@@ -57,4 +57,5 @@ SEXP R_do_slot_assign(SEXP, SEXP, SEXP);
 char *R_alloc(size_t, int);
 void GetRNGstate(void);
 void PutRNGstate(void);
+double unif_rand(void);            /* R_ext/Random.h (pulled in by R.h) */
 #endif

@@ -1353,3 +1353,33 @@ def test_r_default_k_minus_one_past_4096_anchors(oracle):
     np.testing.assert_allclose(ep.values ** 2, w, rtol=1e-9, atol=0)
     VtV = ep.vectors.T @ ep.vectors / n
     assert np.abs(VtV - np.eye(s)).max() < 1e-7
+
+
+@pytest.mark.parametrize("n,d,s,num_init,seed", [(3000, 3, 40, 1, 1), (5000, 16, 64, 2, 7), (2100, 2, 300, 1, 3)])
+def test_kmeans_minibatch(oracle, n, d, s, num_init, seed):
+    """SURVEY 8f-4, second half: the mini-batch k-means of subsample_cpp's "minibatchkmeans" branch (src/Utils.cpp:49-62:
+    ClusterR::MiniBatchKmeans with batch_size = 10 s, kmeans++ on 20 s of the rows, at most 100 iterations, early stop 10)
+    on the device.  (1) Bit for bit the numpy restatement of the same algorithm on the same counter RNG -- centres, 1-NN sizes,
+    iteration count, winning start.  (2) In distribution against the other methods, which is all that can be asked with
+    respect to ClusterR itself (R's RNG): the within-SS is well below that of random rows and in the range of Lloyd's
+    (k-means++ seeding + near-full batches can end BELOW Lloyd-from-random-rows, which stops in a poorer local minimum)."""
+    X = synth.gaussian_mixture(n, d, components=6, seed=seed)
+    U, info, wss = api.kmeans_minibatch(X, s, num_init=num_init, seed=seed)
+    Uo, info_o, wss_o = oracle.np_kmeans_minibatch(X, s, num_init=num_init, seed=seed)
+    assert tuple(info) == tuple(info_o)
+    np.testing.assert_array_equal(U, Uo)
+    assert abs(wss - wss_o) <= 1e-10 * wss_o
+    C = np.asfortranarray(U[:, :d])
+    sizes = np.bincount(oracle.knn(X, C, 1)[:, 0], minlength=s).astype(float)
+    np.testing.assert_array_equal(U[:, d], sizes)                       # the sizes ARE the 1-NN counts (src/Utils.cpp:59-62)
+    assert U[:, d].sum() == n
+    rows = np.sort(synth.random_anchor_rows(n, s, seed=seed))
+    R = np.asfortranarray(X[rows])
+    wss_rand = float(((X - R[oracle.knn(X, R, 1)[:, 0]]) ** 2).sum())
+    _, _, wss_lloyd = api.kmeans_lloyd(X, s, rows, iter_max=100)
+    assert wss < 0.8 * wss_rand and wss < 2.0 * wss_lloyd, (wss_lloyd, wss, wss_rand)
+    # another seed, other centres; the same seed, the same centres
+    U2, _, _ = api.kmeans_minibatch(X, s, num_init=num_init, seed=seed + 1)
+    assert not np.array_equal(U2, U)
+    U3, _, _ = api.kmeans_minibatch(X, s, num_init=num_init, seed=seed)
+    np.testing.assert_array_equal(U3, U)

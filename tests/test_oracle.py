@@ -223,3 +223,25 @@ def test_predict_regression_different_reduces_to_same(oracle):
                                                     np.concatenate([[3.0], nz[1:]]), 1e-3) if m > K else None
         if without is not None:
             np.testing.assert_allclose(with_row, without, rtol=0, atol=1e-6 * np.abs(without).max())
+
+
+def test_minibatch_kmeans_restatement(oracle):
+    """np_kmeans_minibatch (the algorithm behind src/Utils.cpp:49-62, ClusterR's parameters): deterministic in its seed,
+    sizes are the 1-NN counts and add up to n, k-means++ centres are rows of X that the updates have moved at most a little,
+    and the result is better than random rows."""
+    from flgp_amd import synth
+    n, d, s = 1500, 3, 25
+    X = synth.gaussian_mixture(n, d, components=5, seed=2)
+    U, info, wss = oracle.np_kmeans_minibatch(X, s, seed=5)
+    U2, _, wss2 = oracle.np_kmeans_minibatch(X, s, seed=5)
+    np.testing.assert_array_equal(U, U2)
+    assert U.shape == (s, d + 1) and U[:, d].sum() == n and 1 <= info[0] <= 100
+    C = np.asfortranarray(U[:, :d])
+    lab = oracle.knn(X, C, 1)[:, 0]
+    np.testing.assert_array_equal(U[:, d], np.bincount(lab, minlength=s))
+    rows = np.sort(synth.random_anchor_rows(n, s, seed=5))
+    R = np.asfortranarray(X[rows])
+    wss_rand = float(((X - R[oracle.knn(X, R, 1)[:, 0]]) ** 2).sum())
+    assert wss < wss_rand
+    U3, _, _ = oracle.np_kmeans_minibatch(X, s, seed=6)
+    assert not np.array_equal(U3, U)
