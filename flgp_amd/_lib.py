@@ -88,6 +88,8 @@ _SIGNATURES = {
     "flgp_dev_eig_workspace": (c_size_t, [c_int, c_int]),
     "flgp_dev_eig_topk": (c_int, [P, P, c_int, c_int, c_int, c_double, P, P, c_int, P, c_size_t, P]),
     "flgp_dev_bsg_workspace": (c_size_t, [c_int, c_int]),
+    "flgp_dev_bsg_set_trace": (None, [P]),
+    "flgp_dev_jac_set_trace": (None, [P]),
     "flgp_dev_bsg_apply": (c_int, [P, P, c_int, c_int, P, c_int, c_double, c_double, P, P, P, c_size_t, P]),
     "flgp_dev_u_recover_workspace": (c_size_t, [c_int, c_int]),
     "flgp_dev_spectrum_usable": (c_int, [P, P, c_int]),

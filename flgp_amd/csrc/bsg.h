@@ -22,7 +22,7 @@ constexpr int BSG_META = 16;      // ints of device -> host bookkeeping
 struct BsG {
   bool built = false;             // set-up enqueued; `on` is decided by bsg_finish() once the stream has been synchronised
   bool on = false;
-  int s = 0, ntile = 0, nstage = 0;
+  int s = 0, ntile = 0, nstage = 0, nbt = 0;      // nbt: 64-column tiles of the b-wide blocks the workspace was carved for
   // CSR of G in the caller's anchor order
   int *gptr = nullptr, *gcol = nullptr;
   double *gval = nullptr;
@@ -34,6 +34,12 @@ struct BsG {
   int *cnt = nullptr, *blkpos = nullptr, *nk = nullptr, *off = nullptr, *klist = nullptr, *order = nullptr;
   double *pack = nullptr;
   size_t pack_cap = 0;            // blocks
+  // A tile's list is cut into parts of at most `bs_part_cap` stages, each part a task of its own (bsg.hip, product kernel):
+  // (tile, first list entry, entries, part | parts << 16), longest first; slab0[tile] = the tile's first partial-sum
+  // slab, tcnt = arrival counters per (tile, column tile), zero between launches
+  int *parts = nullptr, *parts_u = nullptr, *slab0 = nullptr, *tcnt = nullptr;
+  double *slab = nullptr;
+  size_t part_max = 0, slab_cap = 0;   // parts the lists may hold; parts of split tiles the slab memory holds
   // the scattered rest, rows in permuted order
   int *rcnt = nullptr, *rptr = nullptr, *rcol = nullptr;
   double *rval = nullptr;

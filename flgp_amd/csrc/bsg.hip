@@ -10,7 +10,9 @@ namespace flgp {
 typedef double bd4 __attribute__((ext_vector_type(4)));
 typedef double bd2 __attribute__((ext_vector_type(2)));
 
-enum { BSG_M_NNZ = 0, BSG_M_OFF = 1, BSG_M_TOTAL = 2, BSG_M_RNNZ = 3, BSG_M_MAXNK = 4 };
+enum { BSG_M_NNZ = 0, BSG_M_OFF = 1, BSG_M_TOTAL = 2, BSG_M_RNNZ = 3, BSG_M_MAXNK = 4, BSG_M_NPART = 5, BSG_M_NSLAB = 6, BSG_M_MAXPART = 7 };
+constexpr unsigned BSG_BUF_WORD3 = 0x00020000u;   // raw buffer resource, 32-bit offsets, no swizzle
+typedef unsigned int bu4 __attribute__((ext_vector_type(4)));
 constexpr int BSG_BLK = BSG_SK * BSG_TM;   // doubles per kept block
 constexpr int BSG_DENSE_MIN = 16;          // a 16 x 64 block with at least this many non-zeros goes to the MFMA product
 
@@ -241,7 +243,9 @@ __global__ __launch_bounds__(256) void bsg_count_kernel(const int *__restrict__ 
 __global__ __launch_bounds__(1024) void bsg_lists_kernel(const int *__restrict__ cnt, int ntile, int nstage, long pack_cap,
                                                          int *__restrict__ blkpos, int *__restrict__ nk,
                                                          int *__restrict__ off, int *__restrict__ klist,
-                                                         int *__restrict__ order, int *__restrict__ meta) {
+                                                         int *__restrict__ order, int *__restrict__ meta, int part_cap,
+                                                         int part_max, int slab_cap, int4 *__restrict__ parts_u,
+                                                         int4 *__restrict__ parts, int *__restrict__ slab0) {
   __shared__ int over;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) over = 0;
@@ -281,6 +285,42 @@ __global__ __launch_bounds__(1024) void bsg_lists_kernel(const int *__restrict__
       const int p = blkpos[(size_t)t * nstage + g];
       if (p >= 0) { blkpos[(size_t)t * nstage + g] = o + p; klist[o + p] = g; }
     }
+  }
+  // Tasks of the product: a tile, or -- part_cap > 0 -- the equal parts of a tile whose list is longer than part_cap stages
+  // (their partial sums meet in slabs, bsg_gemm_kernel), longest first.
+  __shared__ int np_sh;
+  if (tid == 0) {
+    int cap = part_cap;
+    for (int pass = 0; pass < 2; ++pass) {
+      int np = 0, nslab = 0;
+      for (int t = 0; t < ntile; ++t) {
+        const int P = (cap > 0 && nk[t] > cap) ? (nk[t] + cap - 1) / cap : 1;
+        np += P; nslab += (P > 1) ? P : 0;
+      }
+      if (np <= part_max && nslab <= slab_cap) break;
+      cap = 0;                                   // does not fit: whole tiles
+    }
+    int np = 0, nslab = 0, mxp = 0;
+    for (int t = 0; t < ntile; ++t) {
+      const int P = (cap > 0 && nk[t] > cap) ? (nk[t] + cap - 1) / cap : 1;
+      slab0[t] = (P > 1) ? nslab : -1;
+      for (int q = 0; q < P; ++q) {
+        const int lo = (int)(((long)q * nk[t]) / P), hi = (int)(((long)(q + 1) * nk[t]) / P);
+        parts_u[np + q] = make_int4(t, lo, hi - lo, q | (P << 16));
+        mxp = (hi - lo > mxp) ? hi - lo : mxp;
+      }
+      np += P; nslab += (P > 1) ? P : 0;
+    }
+    np_sh = np;
+    meta[BSG_M_NPART] = np; meta[BSG_M_NSLAB] = nslab; meta[BSG_M_MAXPART] = mxp;
+  }
+  __syncthreads();
+  const int np = np_sh;
+  for (int u = tid; u < np; u += 1024) {
+    const int4 me = parts_u[u];
+    int rank = 0;
+    for (int v = 0; v < np; ++v) { const int nv = parts_u[v].z; rank += (nv > me.z) || (nv == me.z && v < u); }
+    parts[rank] = me;
   }
 }
 
@@ -416,7 +456,7 @@ __global__ __launch_bounds__(256) void bsg_pre_kernel(const int *__restrict__ rp
 // four waves of 32 x 32 (2 x 2 v_mfma_f64_16x16x4).  LDS row stride 80 doubles: the k and k+1 fragment rows of a
 // ds_read_b64 fall into opposite halves of the 64 banks.
 // ------------------------------------------------------------------------------------------
-constexpr int BSG_LD = 80;
+constexpr int BSG_LD = 64;
 #ifndef BSG_PF
 #define BSG_PF 4
 #endif
@@ -431,57 +471,92 @@ __global__ __launch_bounds__(512, 2) void bsg_gemm_kernel(const double *__restri
                                                           int s, double alpha, const int *__restrict__ order,
                                                           const int *__restrict__ nk, const int *__restrict__ off,
                                                           const int *__restrict__ klist, const double *__restrict__ pack,
-                                                          int ntile, int nbt, int *__restrict__ head) {
+                                                          int ntile, int nbt, int *__restrict__ head,
+                                                          const int4 *__restrict__ parts, int npart,
+                                                          const int *__restrict__ slab0, double *__restrict__ slab,
+                                                          int *__restrict__ tcnt, int xmap,
+                                                          long long *__restrict__ trace) {
   __shared__ double sm[4 * BSG_LROWS * BSG_LD];
   double (*As2)[BSG_LROWS * BSG_LD] = (double (*)[BSG_LROWS * BSG_LD])sm;
   double (*Bs2)[BSG_LROWS * BSG_LD] = (double (*)[BSG_LROWS * BSG_LD])(sm + 2 * BSG_LROWS * BSG_LD);
-  __shared__ int task_sh;
+  __shared__ int task_sh, arrived_sh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int khalf = wave >> 2;                      // which entry of a pair this wave multiplies
   const int wr = ((wave >> 1) & 1) * 32, wc = (wave & 1) * 32;
   const int fr = lane & 15, fk = lane >> 4;
+  const int sw = (fk & 1) << 4;                     // LDS swizzle: odd k rows hold their 16-column groups swapped in pairs
   const int kq = tid >> 5, pr = 2 * (tid & 31);     // staging: row kq (0..15) of both entries, column pair pr
-  const int ntask = ntile * nbt;
-  for (;;) {
-    if (tid == 0) task_sh = atomicAdd(head, 1);
-    __syncthreads();
+  const int ntask = npart * nbt;
+  const size_t x_bytes = (size_t)s * b * 8;
+  const __amdgpu_buffer_rsrc_t rs_b =
+      __builtin_amdgcn_make_buffer_rsrc((void *)Xt, 0, x_bytes < 0xfffffff0u ? (int)(unsigned)x_bytes : (int)0xfffffff0u, BSG_BUF_WORD3);
+  // A workgroup's first task is fixed by its number, the rest come from the queue (which starts behind the fixed ones):
+  // a couple of hundred workgroups asking one word for their first task at the same moment queue up at that word.
+  // xmap: workgroups are dealt round-robin to the 8 XCDs; the fixed tasks are laid out so that the column tiles of a
+  // tile run on ONE XCD (they read the same packed blocks: one fetch into that L2 instead of nbt) and every XCD gets
+  // every 8th tile of the length order.
+  int next_fixed;
+  {
+    const int bid = blockIdx.x, G = gridDim.x;
+    if (xmap) { const int x = bid & 7, j = bid >> 3; next_fixed = ((j / nbt) * 8 + x) * nbt + j % nbt; }
+    else next_fixed = bid;
+    (void)G;
+  }
+  for (bool fixed = true;; fixed = false) {
+    if (!fixed) {
+      if (tid == 0) task_sh = (int)gridDim.x + atomicAdd(head, 1);
+      __syncthreads();
+    }
     // (made wave-uniform for the compiler: the stage numbers kl[si] then come through the scalar cache and its own
     //  counter -- as vector loads they were the youngest entry of the in-order vmcnt queue, and waiting for one drained
     //  every operand load in flight behind it, i.e. the whole prefetch)
-    const int task = __builtin_amdgcn_readfirstlane(task_sh);
-    __syncthreads();
+    const int task = fixed ? next_fixed : __builtin_amdgcn_readfirstlane(task_sh);
+    if (!fixed) __syncthreads();
     if (task >= ntask) return;
-    const int t = order[task / nbt], tb = task % nbt;
-    const int ns = nk[t];
-    if (ns == 0) continue;
+    if (trace && tid == 0) {                        // diagnostic timeline (flgp_dev_bsg_set_trace): start, end, place, length
+      unsigned xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      unsigned hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      trace[4 * (size_t)task + 0] = (long long)wall_clock64();
+      trace[4 * (size_t)task + 2] = ((long long)(xcc & 0xf) << 56) | ((long long)(hw & 0xffff) << 40) | (clock64() & 0xffffffffffll);
+    }
+    const int4 part = parts[task / nbt];            // (tile, first entry, entries, part | parts << 16): scalar loads
+    const int t = part.x, tb = task % nbt;
+    const int ns = part.z;
+    const int nparts = part.w >> 16;
+    if (ns == 0) continue;                          // (an empty list: the tile is one part, nothing to add)
     const int np = (ns + 1) >> 1;                   // pairs of list entries
-    const int *kl = klist + off[t];
-    const double *pk = pack + (size_t)off[t] * BSG_BLK + kq * BSG_TM + pr;
+    const int first = off[t] + part.y;
+    const int *kl = klist + first;
     const int col0 = tb * BSG_TN;
     const int cl = (col0 + pr < b) ? col0 + pr : b - 2;      // columns past the block read a valid pair (never stored)
-    const double *xb = Xt + cl;
     const int last = ns - 1;
-    // Loads are issued unconditionally (past the end of the list: the last entry again, zeroed before use), so that the
-    // number of loads in flight does not depend on the path taken -- with loads under `if` the compiler's wait-count pass
-    // gave up at the joins and waited for all of them every stage.
+    // Loads are issued unconditionally, so that the number of loads in flight does not depend on the path taken -- with
+    // loads under `if` the compiler's wait-count pass gave up at the joins and waited for all of them every stage.  Both
+    // operands come through buffer resources: the packed blocks' one ends with this task's list, so an entry past the
+    // end reads zeros from the bounds check (a choice on the loaded DATA, `live ? a : 0`, had been compiled as load ->
+    // s_waitcnt vmcnt(0) -> v_cndmask right at the load: every stage waited for the loads it had just issued, round 3's
+    // timeline: 1.6 us per pair of stages); X_t's ends with the matrix, so the rows of a last, partial stage read zeros
+    // too.  An address is one v_add of a scalar to the lane's constant: beside the MFMA stream every instruction counts.
+    const __amdgpu_buffer_rsrc_t rs_a =
+        __builtin_amdgcn_make_buffer_rsrc((void *)(pack + (size_t)first * BSG_BLK), 0, ns * BSG_BLK * 8, BSG_BUF_WORD3);
+    const unsigned lane_a = (unsigned)((kq * BSG_TM + pr) * 8), lane_b = (unsigned)((kq * b + cl) * 8);
+    const unsigned stage_b = (unsigned)(BSG_SK * b * 8);
     auto load = [&](int pj, bd2 (&ra)[2], bd2 (&rb)[2]) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        int si = 2 * pj + e;
-        const bool live = si <= last;
-        si = live ? si : last;
-        int k = kl[si] * BSG_SK + kq;
-        const bd2 a = *(const bd2 *)(pk + (size_t)si * BSG_BLK);
-        ra[e] = live ? a : bd2{0.0, 0.0};
-        k = (k < s) ? k : s - 1;                             // rows past the matrix meet zeros of the packed block
-        rb[e] = *(const bd2 *)(xb + (size_t)k * b);
+        const int si = 2 * pj + e;
+        const int sb = si < last ? si : last;
+        ra[e] = __builtin_bit_cast(bd2, __builtin_amdgcn_raw_buffer_load_b128(rs_a, lane_a + (unsigned)si * (BSG_BLK * 8), 0, 0));
+        rb[e] = __builtin_bit_cast(bd2, __builtin_amdgcn_raw_buffer_load_b128(rs_b, lane_b + (unsigned)kl[sb] * stage_b, 0, 0));
       }
     };
     auto stash = [&](int buf, const bd2 (&ra)[2], const bd2 (&rb)[2]) {
 #pragma unroll
       for (int e = 0; e < 2; ++e) {
-        *(bd2 *)(&As2[buf][(e * BSG_SK + kq) * BSG_LD + pr]) = ra[e];
-        *(bd2 *)(&Bs2[buf][(e * BSG_SK + kq) * BSG_LD + pr]) = rb[e];
+        *(bd2 *)(&As2[buf][(e * BSG_SK + kq) * BSG_LD + (pr ^ ((kq & 1) << 4))]) = ra[e];
+        *(bd2 *)(&Bs2[buf][(e * BSG_SK + kq) * BSG_LD + (pr ^ ((kq & 1) << 4))]) = rb[e];
       }
     };
     bd4 acc[2][2];
@@ -496,9 +571,9 @@ __global__ __launch_bounds__(512, 2) void bsg_gemm_kernel(const double *__restri
       for (int kk = 0; kk < BSG_SK; kk += 4) {
         double fa[2], fb[2];
 #pragma unroll
-        for (int mi = 0; mi < 2; ++mi) fa[mi] = As[kk * BSG_LD + mi * 16];
+        for (int mi = 0; mi < 2; ++mi) fa[mi] = As[kk * BSG_LD + ((mi * 16) ^ sw)];
 #pragma unroll
-        for (int ni = 0; ni < 2; ++ni) fb[ni] = Bs[kk * BSG_LD + ni * 16];
+        for (int ni = 0; ni < 2; ++ni) fb[ni] = Bs[kk * BSG_LD + ((ni * 16) ^ sw)];
 #pragma unroll
         for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
@@ -516,7 +591,7 @@ __global__ __launch_bounds__(512, 2) void bsg_gemm_kernel(const double *__restri
 #pragma unroll
         for (int reg = 0; reg < 4; ++reg) {
           const int i = t * BSG_TM + wr + mi * 16 + fk + 4 * reg, c = col0 + wc + ni * 16 + fr;
-          base[mi][ni][reg] = (khalf == 0 && i < s && c < b) ? out[(size_t)i * b + c] : 0.0;
+          base[mi][ni][reg] = (khalf == 0 && nparts == 1 && i < s && c < b) ? out[(size_t)i * b + c] : 0.0;
         }
     // the operands of BSG_PF pairs are in flight in registers (pair j in slot j % BSG_PF), one further pair sits in LDS
     bd2 ra[BSG_PF][2], rb[BSG_PF][2];
@@ -557,6 +632,72 @@ __global__ __launch_bounds__(512, 2) void bsg_gemm_kernel(const double *__restri
     }
     __syncthreads();
     if (khalf == 0) {
+#pragma unroll
+      for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+          for (int reg = 0; reg < 4; ++reg) acc[mi][ni][reg] += xch[((wave * 16) + (mi * 2 + ni) * 4 + reg) * 64 + lane];
+    }
+    bool write = true;                              // uniform over the workgroup
+    if (nparts > 1) {
+      // The partial sum goes to this part's slab, write-through (sc1: the parts of a tile may sit on different XCDs, whose
+      // L2s do not see each other); every storing wave drains its stores, the workgroup meets, one lane draws a ticket.
+      // The part that draws the last ticket adds the slabs in part order (sc1 loads: they pass the L1) on top of what
+      // the first launch left in `out`.  Deterministic: the sum does not depend on who arrives last.
+      const int tile_slab = slab0[t];
+      double *my = slab + ((size_t)(tile_slab + (part.w & 0xffff)) * nbt + tb) * (BSG_TM * BSG_TN);
+      if (khalf == 0) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)my, 0, BSG_TM * BSG_TN * 8, BSG_BUF_WORD3);
+#pragma unroll
+        for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+          for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const bd2 v = bd2{acc[mi][ni][2 * h], acc[mi][ni][2 * h + 1]};
+              const unsigned o = (unsigned)(((wave * 8 + (mi * 2 + ni) * 2 + h) * 64 + lane) * 16);
+              __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(bu4, v), rs, o, 0, 16);
+            }
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0)
+        arrived_sh = __hip_atomic_fetch_add(&tcnt[t * nbt + tb], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __syncthreads();
+      write = arrived_sh == nparts - 1;
+      if (write) {
+        if (tid == 0) __hip_atomic_store(&tcnt[t * nbt + tb], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (khalf == 0) {
+#pragma unroll
+          for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+              for (int reg = 0; reg < 4; ++reg) {
+                const int i = t * BSG_TM + wr + mi * 16 + fk + 4 * reg, c = col0 + wc + ni * 16 + fr;
+                base[mi][ni][reg] = (i < s && c < b) ? out[(size_t)i * b + c] : 0.0;
+                acc[mi][ni][reg] = 0.0;
+              }
+          for (int q = 0; q < nparts; ++q) {
+            const double *sl = slab + ((size_t)(tile_slab + q) * nbt + tb) * (BSG_TM * BSG_TN);
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void *)sl, 0, BSG_TM * BSG_TN * 8, BSG_BUF_WORD3);
+#pragma unroll
+            for (int mi = 0; mi < 2; ++mi)
+#pragma unroll
+              for (int ni = 0; ni < 2; ++ni)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                  const unsigned o = (unsigned)(((wave * 8 + (mi * 2 + ni) * 2 + h) * 64 + lane) * 16);
+                  const bd2 v = __builtin_bit_cast(bd2, __builtin_amdgcn_raw_buffer_load_b128(rs, o, 0, 16));
+                  acc[mi][ni][2 * h] += v[0];
+                  acc[mi][ni][2 * h + 1] += v[1];
+                }
+          }
+        }
+      }
+    }
+    if (khalf == 0 && write) {
       // D(row = fk + 4 reg, col = fr) of each 16 x 16 tile; the 16 lanes of one fk write 128 contiguous bytes
 #pragma unroll
       for (int mi = 0; mi < 2; ++mi)
@@ -566,12 +707,17 @@ __global__ __launch_bounds__(512, 2) void bsg_gemm_kernel(const double *__restri
 #pragma unroll
           for (int reg = 0; reg < 4; ++reg) {
             const int i = t * BSG_TM + wr + mi * 16 + fk + 4 * reg;
-            const double v = acc[mi][ni][reg] + xch[((wave * 16) + (mi * 2 + ni) * 4 + reg) * 64 + lane];
-            if (i < s && c < b) out[(size_t)i * b + c] = base[mi][ni][reg] + alpha * v;
+            if (i < s && c < b) out[(size_t)i * b + c] = base[mi][ni][reg] + alpha * acc[mi][ni][reg];
           }
         }
     }
     __syncthreads();                               // the exchange buffer is stage memory of the next task
+    if (trace && tid == 0) {
+      trace[4 * (size_t)task + 1] = (long long)wall_clock64();
+      const long long c0 = trace[4 * (size_t)task + 2];
+      trace[4 * (size_t)task + 2] = (c0 & ~0xffffffffffll) | ((clock64() - c0) & 0xffffffffffll);   // shader cycles of the task
+      trace[4 * (size_t)task + 3] = ((long long)blockIdx.x << 32) | (unsigned)ns;
+    }
   }
 }
 
@@ -688,7 +834,7 @@ size_t bsg_workspace_bytes(int s, int b) {   // what bsg_carve takes, measured b
 void bsg_carve(BsG &g, char *&p, int s, int b) {
   auto take = [&](size_t bytes) { char *q = p; p += al(bytes); return q; };
   const size_t nt = (s + BSG_TM - 1) / BSG_TM, ng = (s + BSG_SK - 1) / BSG_SK;
-  g.s = s; g.ntile = (int)nt; g.nstage = (int)ng;
+  g.s = s; g.ntile = (int)nt; g.nstage = (int)ng; g.nbt = (b + BSG_TN - 1) / BSG_TN;
   g.csr_cap = bsg_csr_cap(s); g.rem_cap = g.csr_cap / 4 + 64; g.pack_cap = bsg_pack_cap(s);
   g.gptr = (int *)take(sizeof(int) * (s + 1)); g.gcol = (int *)take(sizeof(int) * g.csr_cap);
   g.gval = (double *)take(sizeof(double) * g.csr_cap);
@@ -704,6 +850,16 @@ void bsg_carve(BsG &g, char *&p, int s, int b) {
   g.nk = (int *)take(sizeof(int) * (nt + 1)); g.off = (int *)take(sizeof(int) * (nt + 1));
   g.order = (int *)take(sizeof(int) * (nt + 1)); (void)take(sizeof(int) * (nt + 1));
   g.klist = (int *)take(sizeof(int) * nt * ng);
+  {
+    const size_t nbt = (size_t)(b + BSG_TN - 1) / BSG_TN;
+    g.part_max = g.pack_cap / 8 + nt;
+    g.slab_cap = std::min(g.part_max, (size_t)(256u << 20) / (nbt * BSG_TM * BSG_TN * sizeof(double)));
+    g.slab_cap = std::min(g.slab_cap, (size_t)1024);
+    g.parts = (int *)take(sizeof(int) * 4 * g.part_max); g.parts_u = (int *)take(sizeof(int) * 4 * g.part_max);
+    g.slab0 = (int *)take(sizeof(int) * (nt + 1));
+    g.tcnt = (int *)take(sizeof(int) * (nt * nbt + 4));
+    g.slab = (double *)take(sizeof(double) * g.slab_cap * nbt * BSG_TM * BSG_TN);
+  }
   g.pack = (double *)take(sizeof(double) * BSG_BLK * g.pack_cap);
   g.rptr = (int *)take(sizeof(int) * (s + 1)); (void)take(sizeof(int) * (s + 1));
   g.rcol = (int *)take(sizeof(int) * g.rem_cap); g.rval = (double *)take(sizeof(double) * g.rem_cap);
@@ -800,8 +956,11 @@ int bsg_setup(hipStream_t st, const double *dG, int ldg, int s, BsG &g, hipStrea
   hipLaunchKernelGGL(bsg_iperm_kernel, dim3(ceil_div(s, 256)), dim3(256), 0, st, g.perm, s, g.iperm);
   hipLaunchKernelGGL(bsg_count_kernel, dim3(g.ntile), dim3(256), sizeof(int) * g.nstage, st, g.gptr, g.gcol, g.perm, g.iperm, s,
                      g.nstage, g.cnt);
+  FLGP_HIP(hipMemsetAsync(g.tcnt, 0, sizeof(int) * ((size_t)g.ntile * g.nbt + 4), st));
+  const int part_cap = tuning("eig_bs_part_cap", 0) < 8 ? 0 : tuning("eig_bs_part_cap", 0);
   hipLaunchKernelGGL(bsg_lists_kernel, dim3(1), dim3(1024), 0, st, g.cnt, g.ntile, g.nstage, (long)g.pack_cap, g.blkpos,
-                     g.nk, g.off, g.klist, g.order, g.meta);
+                     g.nk, g.off, g.klist, g.order, g.meta, part_cap, (int)g.part_max, (int)g.slab_cap, (int4 *)g.parts_u,
+                     (int4 *)g.parts, g.slab0);
   hipLaunchKernelGGL(bsg_pack_kernel, dim3(g.nstage, g.ntile), dim3(256), 0, st, dG, ldg, s, g.nstage, g.perm, g.blkpos,
                      g.meta, g.pack);
   hipLaunchKernelGGL(bsg_rem_kernel, dim3(rows4), dim3(256), 0, st, g.gptr, g.gcol, g.gval, g.perm, g.iperm, g.blkpos, g.meta,
@@ -839,8 +998,19 @@ void bsg_finish(BsG &g) {
     fprintf(stderr, "[flgp eig] block-sparse G: %d non-zeros, %.1f %% of the %dx%d blocks kept for the MFMA product (max %d of %d stages "
             "per tile), %d scattered non-zeros\n", g.h_meta[BSG_M_NNZ], 100.0 * frac, BSG_TM, BSG_SK, g.h_meta[BSG_M_MAXNK], g.nstage,
             g.h_meta[BSG_M_RNNZ]);
+  if (tuning("eig_verbose", 0) > 1) {     // list lengths of the tiles, longest first
+    std::vector<int> nk(g.ntile);
+    if (hipMemcpy(nk.data(), g.nk, sizeof(int) * g.ntile, hipMemcpyDeviceToHost) == hipSuccess) {
+      std::sort(nk.begin(), nk.end(), [](int a, int b) { return a > b; });
+      fprintf(stderr, "[flgp eig] kept stages per tile:");
+      for (int v : nk) fprintf(stderr, " %d", v);
+      fprintf(stderr, "\n");
+    }
+  }
   g.on = frac <= 0.01 * std::min(50, tuning("eig_bs_max_pct", 50));
 }
+
+static long long *g_bsg_trace = nullptr;     // diagnostic: 4 words per task of the product kernel (see flgp_dev_bsg_set_trace)
 
 int bsg_product(hipStream_t st, BsG &g, const double *Xt, int b, double alpha, double beta, const double *Et, double gamma,
                 const double *E2t, double *out_t) {
@@ -855,13 +1025,21 @@ int bsg_product(hipStream_t st, BsG &g, const double *Xt, int b, double alpha, d
   }
   FLGP_TRY(check_launch("bsg_pre_kernel"));
   const int nbt = ceil_div(b, BSG_TN);
-  const int ntask = g.ntile * nbt;
-  int grid = std::min(ntask, std::max(64, tuning("eig_bs_wgs", 256)));
+  if (nbt != g.nbt) { set_error("bsg_product: block width differs from the one the workspace was carved for"); return FLGP_ERR_INVALID; }
+  const int npart = g.h_meta[BSG_M_NPART];
+  const int ntask = npart * nbt;
+  int grid = std::max(64, tuning("eig_bs_wgs", 256));
+  int xmap = tuning("eig_bs_xmap", 1);
+  if (xmap) {                                       // the layout of the fixed tasks needs (grid / 8) % nbt == 0
+    const int unit = 8 * nbt;
+    if (grid >= unit) grid = grid / unit * unit; else xmap = 0;
+  }
+  if (!xmap) grid = std::min(grid, ntask);
   {
     const double fl = 2.0 * (double)BSG_BLK * (double)g.h_meta[BSG_M_TOTAL] * (double)b;
     ProfScope ps("bsg_gemm_kernel", st, fl);
     hipLaunchKernelGGL(bsg_gemm_kernel, dim3(grid), dim3(512), 0, st, Xt, out_t, b, s, alpha, g.order, g.nk, g.off, g.klist,
-                       g.pack, g.ntile, nbt, head);
+                       g.pack, g.ntile, nbt, head, (const int4 *)g.parts, npart, g.slab0, g.slab, g.tcnt, xmap, g_bsg_trace);
   }
   FLGP_TRY(check_launch("bsg_gemm_kernel"));
   ++g.launches;
@@ -890,6 +1068,8 @@ __global__ void bsg_from_t_kernel(const double *__restrict__ in_t, int s, int b,
 
 extern "C" size_t flgp_dev_bsg_workspace(int s, int b) { return bsg_workspace_bytes(s, b) + 1024; }
 
+extern "C" void flgp_dev_bsg_set_trace(void *d_trace) { flgp::g_bsg_trace = (long long *)d_trace; }
+
 extern "C" int flgp_dev_bsg_apply(void *stream, const double *dG, int ldg, int s, const double *dX, int b, double alpha,
                                   double beta, const double *dE, double *dOut, void *d_work, size_t work_bytes,
                                   int *info) {
@@ -904,6 +1084,7 @@ extern "C" int flgp_dev_bsg_apply(void *stream, const double *dG, int ldg, int s
   bsg_finish(g);
   if (info) {
     info[0] = g.on ? 1 : 0; info[1] = g.h_meta[BSG_M_NNZ]; info[2] = g.h_meta[BSG_M_TOTAL]; info[3] = g.h_meta[BSG_M_RNNZ];
+    info[4] = g.h_meta[BSG_M_NPART]; info[5] = g.h_meta[BSG_M_NSLAB];
   }
   if (!g.built || g.h_meta[BSG_M_OFF]) { set_error("bsg_apply: the matrix is too dense for the block-sparse product"); return FLGP_ERR_INVALID; }
   const long tot = (long)s * b;

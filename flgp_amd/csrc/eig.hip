@@ -295,11 +295,19 @@ __global__ __launch_bounds__(1024) void jac_round_kernel(double *__restrict__ B,
 typedef double jd4 __attribute__((ext_vector_type(4)));
 typedef double d2v __attribute__((ext_vector_type(2)));
 
+// diagnostic (flgp_dev_jac_set_trace): word 0 = launches recorded so far, then 8 words per launch of jac_block_kernel,
+// written by workgroup 0: 100 MHz wall clock at start / panel in LDS / Gram block summed / small problem solved /
+// B panel stored / end, cross_only, round
+static long long *g_jac_trace = nullptr;
+__device__ __forceinline__ void jac_stamp(long long *tr, int slot) {
+  if (tr && blockIdx.x == 0 && threadIdx.x == 0) tr[slot] = (long long)wall_clock64();
+}
+
 template <int NLOC>
 __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B, double *__restrict__ V, int b,
                                                          int ldb, int nbc, int round, double tol,
                                                          int *__restrict__ flags, int local_sweeps,
-                                                         int cross_only) {
+                                                         int cross_only, long long *__restrict__ trace) {
   constexpr int WB = NLOC / 2;        // block-column width
   constexpr int NP = NLOC / 2;        // pairs per local round
   constexpr int NT16 = NLOC / 16;     // 16-wide tiles per side
@@ -310,6 +318,12 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
   __shared__ int round_rot[3];
   if (flags[1]) return;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  long long *tr = nullptr;
+  if (trace && blockIdx.x == 0) {       // launches of one solve follow each other on one stream: the count is stable while this one runs
+    const long long n = trace[0];
+    tr = (n < 4096) ? trace + 1 + 8 * n : nullptr;
+  }
+  jac_stamp(tr, 0);
   if (tid < 3) round_rot[tid] = 0;
   if (tid == 0) visit_rot = 0;
   int I, J;
@@ -380,6 +394,7 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
     }
   }
   __syncthreads();
+  jac_stamp(tr, 1);
   // ---- Gram block on the matrix cores
   if (wave < TILES * KP) {
     const int tile = wave % TILES, kp = wave / TILES;
@@ -403,6 +418,7 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
     Wm[e] = (e / NLOC == e % NLOC) ? 1.0 : 0.0;
   }
   __syncthreads();
+  jac_stamp(tr, 2);
   // ---- two-sided cyclic Jacobi on Gm, rotations accumulated in Wm.
   // Per round: NP leader lanes turn (Gm_pp, Gm_qq, Gm_pq) into rotation coefficients, then every
   // thread rebuilds ONE element of J^T Gm J and of Wm J from the old buffers into the other
@@ -466,6 +482,8 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
     __syncthreads();
   }
   __syncthreads();
+  jac_stamp(tr, 3);
+  if (tr && tid == 0) { tr[6] = cross_only; tr[7] = round; tr[4] = tr[5] = 0; trace[0] = trace[0] + 1; }
   if (!visit_rot) return;   // the NLOC columns were orthogonal to the threshold already: panels untouched
   if (Wc != Wm) {   // an odd number of rounds ran: move the result where apply_w reads it
     for (int e = tid; e < NLOC * NLOC; e += 1024) Wm[e] = Wc[e];
@@ -480,6 +498,7 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
   __syncthreads();
   store_panel(B);
   __syncthreads();
+  jac_stamp(tr, 4);
   if (v_early) {
 #pragma unroll
     for (int cc_ = 0; cc_ < NLOC / 16; ++cc_)
@@ -495,6 +514,8 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
   apply_w();
   __syncthreads();
   store_panel(V);
+  __syncthreads();
+  jac_stamp(tr, 5);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1094,10 +1115,10 @@ static int jacobi_run(hipStream_t st, int b, EigWork &w, std::vector<double> &h_
         hipLaunchKernelGGL(jac_stream_kernel, dim3(p.nbc / 2), dim3(1024), 0, st, JB, JV, b, b, p.nbc, round, tol, w.flags);
       else if (p.nloc == 32)
         hipLaunchKernelGGL(jac_block_kernel<32>, dim3(p.nbc / 2), dim3(1024), p.lds, st, JB, JV, b, b, p.nbc, round,
-                           tol, w.flags, tuning("jacobi_local_sweeps", 1), cross);
+                           tol, w.flags, tuning("jacobi_local_sweeps", 1), cross, g_jac_trace);
       else if (p.nloc == 16)
         hipLaunchKernelGGL(jac_block_kernel<16>, dim3(p.nbc / 2), dim3(1024), p.lds, st, JB, JV, b, b, p.nbc, round,
-                           tol, w.flags, tuning("jacobi_local_sweeps", 1), cross);
+                           tol, w.flags, tuning("jacobi_local_sweeps", 1), cross, g_jac_trace);
       else
         hipLaunchKernelGGL(jac_round_kernel, dim3(p.nbc / 2), dim3(p.nt), p.lds, st, JB, JV, b, b, p.w, p.nbc,
                            round, tol, w.flags, 1);
@@ -1876,3 +1897,5 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   FLGP_HIP(stream_wait(st));
   return FLGP_OK;
 }
+
+extern "C" void flgp_dev_jac_set_trace(void *d_trace) { flgp::g_jac_trace = (long long *)d_trace; }

@@ -522,13 +522,18 @@ def test_eig_blocksparse_matches_dense(stages):
         L.flgp_set_tuning(b"eig_blocksparse", 1)
 
 
-@pytest.mark.parametrize("s,b,density", [(700, 48, 0.03), (1100, 64, 0.02), (2000, 256, 0.01), (1536, 80, 0.05)])
-def test_blocksparse_product_matches_dense(stages, s, b, density):
+@pytest.mark.parametrize("s,b,density,part_cap", [(700, 48, 0.03, 24), (1100, 64, 0.02, 24), (2000, 256, 0.01, 24),
+                                                  (1536, 80, 0.05, 24), (2000, 256, 0.06, 8), (1536, 80, 0.1, 8),
+                                                  (2000, 256, 0.06, 0)])
+def test_blocksparse_product_matches_dense(stages, s, b, density, part_cap):
     """csrc/bsg.hip on its own: alpha G X + beta E through the ordering, the kept 64 x 16 blocks (MFMA) and the CSR
     remainder equals the dense product to rounding -- for a banded-plus-scattered symmetric matrix (blocks AND a
-    remainder, tile / stage / column-tile edges that do not divide s or b), including rows without any entry."""
+    remainder, tile / stage / column-tile edges that do not divide s or b), including rows without any entry.  With
+    a small `eig_bs_part_cap` the tiles' lists are cut into parts whose partial sums meet in slabs inside the launch
+    (the last part to arrive adds them in part order): same result, launch after launch (the arrival counters reset)."""
     import ctypes
     L = _lib.lib()
+    L.flgp_set_tuning(b"eig_bs_part_cap", part_cap)
     rng = np.random.default_rng(s + b)
     G = np.zeros((s, s))
     band = max(8, int(density * s))
@@ -548,17 +553,29 @@ def test_blocksparse_product_matches_dense(stages, s, b, density):
     out = torch.empty((b, s), dtype=torch.float64, device="cuda")
     wb = L.flgp_dev_bsg_workspace(s, b)
     work = torch.empty((wb // 8 + 1,), dtype=torch.float64, device="cuda")
-    info = (ctypes.c_int * 4)()
+    info = (ctypes.c_int * 6)()
     st = torch.cuda.current_stream().cuda_stream
-    for alpha, beta, e in ((1.0, 0.0, None), (0.7, -1.3, dE)):
-        _lib.check(L.flgp_dev_bsg_apply(st, dG.data_ptr(), s, s, dX.data_ptr(), b, alpha, beta,
-                                        e.data_ptr() if e is not None else None, out.data_ptr(), work.data_ptr(), wb,
-                                        ctypes.addressof(info)))
-        ref = alpha * (G @ X) + (beta * E if e is not None else 0.0)
-        got = to_np_cm(out)
-        assert info[1] == np.count_nonzero(G)
-        assert info[2] > 0 and info[3] > 0, "the case must exercise both the blocks and the remainder"
-        np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+    try:
+        prev = {}
+        for alpha, beta, e in ((1.0, 0.0, None), (0.7, -1.3, dE), (1.0, 0.0, None)):
+            _lib.check(L.flgp_dev_bsg_apply(st, dG.data_ptr(), s, s, dX.data_ptr(), b, alpha, beta,
+                                            e.data_ptr() if e is not None else None, out.data_ptr(), work.data_ptr(), wb,
+                                            ctypes.addressof(info)))
+            ref = alpha * (G @ X) + (beta * E if e is not None else 0.0)
+            got = to_np_cm(out)
+            assert info[1] == np.count_nonzero(G)
+            assert info[2] > 0 and info[3] > 0, "the case must exercise both the blocks and the remainder"
+            ntile = (s + 63) // 64
+            if part_cap == 8:
+                assert info[5] > 0 and info[4] > ntile, "the case must cut tiles into parts"
+            if part_cap == 0:
+                assert info[5] == 0 and info[4] == ntile
+            np.testing.assert_allclose(got, ref, rtol=0, atol=1e-12 * np.abs(ref).max())
+            if (alpha, beta) in prev:
+                assert np.array_equal(prev[(alpha, beta)], got), "the same product twice: bit-identical"
+            prev[(alpha, beta)] = got
+    finally:
+        L.flgp_set_tuning(b"eig_bs_part_cap", 0)
 
 
 # ------------------------------------------------------------------------------ spectrum + heat kernel
