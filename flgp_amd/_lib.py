@@ -23,6 +23,7 @@ _SIGNATURES = {
     "flgp_version": (c_char_p, []),
     "flgp_device_count": (c_int, []),
     "flgp_dev_pool_release": (c_size_t, []),
+    "flgp_release_pinned": (None, []),
     "flgp_set_device": (c_int, [c_int]),
     "flgp_parse_gl": (c_int, [c_char_p]),
     "flgp_set_tuning": (c_int, [c_char_p, c_int]),
@@ -93,6 +94,7 @@ _SIGNATURES = {
     "flgp_dev_bsg_apply": (c_int, [P, P, c_int, c_int, P, c_int, c_double, c_double, P, P, P, c_size_t, P]),
     "flgp_dev_u_recover_workspace": (c_size_t, [c_int, c_int]),
     "flgp_dev_spectrum_usable": (c_int, [P, P, c_int]),
+    "flgp_dev_spectrum_usable_route": (c_int, [P, P, c_int, c_int]),
     "flgp_dev_u_recover": (c_int, [P, P, P, c_int, c_int, P, c_int, c_int, P, c_int, c_double, c_int, P, c_int, P, P]),
     "flgp_dev_hk": (c_int, [P, P, c_int, c_double, P, c_int, P, c_int, c_int, P, c_int, P, c_int, c_int,
                             P, c_int, P]),

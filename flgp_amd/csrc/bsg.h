@@ -46,20 +46,30 @@ struct BsG {
   size_t rem_cap = 0;
   // per-row figures of G gathered while the CSR is counted: absolute column sums, diagonal
   double *colabs = nullptr, *diag = nullptr, *bounds = nullptr;
-  double h_bounds[2] = {0.0, 0.0};   // 1-norm of G (>= lambda_max), trace of G; valid like h_meta
+  // Host copies of what the set-up reads back (asynchronously: valid after the next synchronisation of their stream).
+  // They point at the struct's own arrays unless the caller hands in pinned slots before bsg_setup (bsg_host_slots): a
+  // copy into pageable memory may block the host until the stream reaches it, and one into a stack frame that an early
+  // return has left is a write into dead memory -- the eigensolver passes slots its per-thread context owns.
+  double h_bounds_own[2] = {0.0, 0.0};
+  double *h_bounds = h_bounds_own;   // 1-norm of G (>= lambda_max), trace of G
   int *meta = nullptr;            // device: see BSG_M_* in bsg.hip
   int *head = nullptr;            // work-queue heads of the product kernel (ring of 2)
   double *lz = nullptr;           // Lanczos vectors / partial sums / (alpha, beta)
-  double h_ab[64] = {0};          // (alpha_k, beta_k) of the Lanczos steps, valid after lz_ev
+  double h_ab_own[64] = {0};
+  double *h_ab = h_ab_own;        // (alpha_k, beta_k) of the Lanczos steps, valid after lz_ev
   bool lanczos = false;
   hipEvent_t lz_ev = nullptr;
   double lambda_lo = 0.0;         // safe-side estimate of lambda_min(G) (0 when there is none): set by bsg_finish
   double *T[3] = {nullptr, nullptr, nullptr};   // b x s blocks of the transposed filter
-  int h_meta[BSG_META] = {0};     // host copy, valid after the stream has been synchronised
+  int h_meta_own[BSG_META] = {0};
+  int *h_meta = h_meta_own;       // host copy of meta
   int launches = 0;               // products issued
   std::vector<int> h_perm;        // source of an asynchronous upload: lives as long as the struct
 };
 
+constexpr size_t BSG_HOST_SLOT_BYTES = sizeof(double) * (2 + 64) + sizeof(int) * BSG_META;
+// point the read-back copies at caller-owned (pinned) host memory of BSG_HOST_SLOT_BYTES bytes
+void bsg_host_slots(BsG &g, void *slots);
 size_t bsg_workspace_bytes(int s, int b);
 // carve the members out of a workspace (advances p)
 void bsg_carve(BsG &g, char *&p, int s, int b);

@@ -824,6 +824,13 @@ static size_t bsg_pack_cap(int s) {
   return nt * ng / 2 + 1;
 }
 
+void bsg_host_slots(BsG &g, void *slots) {
+  double *d = (double *)slots;
+  g.h_bounds = d; g.h_ab = d + 2; g.h_meta = (int *)(d + 2 + 64);
+  for (int q = 0; q < 2 + 64; ++q) d[q] = 0.0;
+  for (int q = 0; q < BSG_META; ++q) g.h_meta[q] = 0;
+}
+
 size_t bsg_workspace_bytes(int s, int b) {   // what bsg_carve takes, measured by carving at address 0
   BsG g;
   char *p = nullptr;

@@ -4,6 +4,7 @@
 #include "common.h"
 #include <chrono>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 #include <cstring>
 #include <cmath>
@@ -27,7 +28,7 @@ extern "C" int flgp_dev_se_weights_den(void *stream, const int *d_knn_idx, const
 // caller of flgp_dev_eig_topk that goes on to flgp_dev_u_recover asks here first (the host spectrum did, the
 // bandwidth grid and the sharded driver did not): FLGP_OK, or FLGP_ERR_INVALID / FLGP_ERR_NOCONV with the message.
 // Synchronises the stream (flgp_dev_eig_topk has done so already: the copy is K doubles).
-extern "C" int flgp_dev_spectrum_usable(void *stream, const double *d_eig, int K) {
+extern "C" int flgp_dev_spectrum_usable_route(void *stream, const double *d_eig, int K, int full_decomposition) {
   hipStream_t st = (hipStream_t)stream;
   FLGP_REQUIRE(d_eig && K >= 1, "spectrum_usable: bad arguments");
   std::vector<double> hv((size_t)K);
@@ -35,13 +36,22 @@ extern "C" int flgp_dev_spectrum_usable(void *stream, const double *d_eig, int K
   FLGP_HIP(hipStreamSynchronize(st));
   const double top = hv[0], low = hv[K - 1];
   if (!(top > 0.0) || !std::isfinite(top)) { set_error("spectrum: the similarity matrix is zero or not finite"); return FLGP_ERR_INVALID; }
-  if (!(low > 1e-24 * top)) {
-    set_error("spectrum: singular value %d of A is zero to working precision (sigma^2 = %.3e, sigma_1^2 = %.3e): K = %d reaches "
-              "into the null space of the similarity matrix, whose left vectors the Gram route cannot recover -- choose a smaller K",
-              K, low, top, K);
+  // What the solver delivered is what bounds the left vectors u = A v / sigma: the block solver stops at
+  // residuals of 5e-11 lambda_1, so an eigenvalue below ~1e-10 lambda_1 is rounding noise and its u noise amplified by
+  // lambda_1 / lambda; the full decomposition (K == s: Jacobi to working precision) resolves eigenvalues down to
+  // ~1e3 eps lambda_1.  Below that the Gram route has nothing to offer -- the reference's SVD of A itself would.
+  const double floor_rel = full_decomposition ? std::pow(10.0, -(double)tuning("spectrum_floor_exp_full", 13))
+                                              : std::pow(10.0, -(double)tuning("spectrum_floor_exp", 10));
+  if (!(low > floor_rel * top)) {
+    set_error("spectrum: sigma_%d^2 = %.3e is below %.0e sigma_1^2 (= %.3e), what the %s resolves: K = %d reaches into the "
+              "(numerical) null space of the similarity matrix, whose left vectors the Gram route cannot recover -- choose a "
+              "smaller K", K, low, floor_rel, top, full_decomposition ? "full decomposition" : "block eigensolver", K);
     return FLGP_ERR_NOCONV;
   }
   return FLGP_OK;
+}
+extern "C" int flgp_dev_spectrum_usable(void *stream, const double *d_eig, int K) {
+  return flgp_dev_spectrum_usable_route(stream, d_eig, K, 0);
 }
 
 namespace {
@@ -258,9 +268,11 @@ int spectrum(Sim &S, hipStream_t st, int K, int root, Spectrum &P, int *info) {
   FLGP_TRY(P.work.alloc(wb));
   FLGP_TRY(P.eig.alloc(sizeof(double) * (size_t)K));
   FLGP_TRY(P.V.alloc(sizeof(double) * (size_t)S.s * K));
+  int solve_info[4] = {0, 0, 0, 0};
   FLGP_TRY(flgp_dev_eig_topk(st, P.G.as<double>(), S.s, S.s, K, 0.0, P.eig.as<double>(), P.V.as<double>(), S.s,
-                             P.work.p, wb, info));
-  FLGP_TRY(flgp_dev_spectrum_usable(st, P.eig.as<double>(), K));
+                             P.work.p, wb, solve_info));
+  if (info) for (int q = 0; q < 4; ++q) info[q] = solve_info[q];
+  FLGP_TRY(flgp_dev_spectrum_usable_route(st, P.eig.as<double>(), K, solve_info[2]));
   // u = A v / sigma, vectors = u sqrt(n), values = sigma^2 (or sigma if root)  (:153-158)
   FLGP_TRY(P.values.alloc(sizeof(double) * (size_t)K));
   FLGP_TRY(P.vectors.alloc(sizeof(double) * (size_t)S.n * K));
@@ -294,24 +306,60 @@ bool is_range(const int *idx, int cnt) {
 // lifetime of the process (pinning 1 GB costs more than the whole call).
 // ------------------------------------------------------------------------------------------
 struct PinnedRing {
-  std::mutex mu;
   void *buf[2] = {nullptr, nullptr};
   size_t bytes = 0;
-  int ensure(size_t need) {
-    if (need <= bytes) return FLGP_OK;
+  bool busy = false;
+  void drop() {
     for (int q = 0; q < 2; ++q) { if (buf[q]) (void)hipHostFree(buf[q]); buf[q] = nullptr; }
     bytes = 0;
+  }
+  int ensure(size_t need) {
+    if (need <= bytes) return FLGP_OK;
+    drop();
     for (int q = 0; q < 2; ++q)
       if (hipHostMalloc(&buf[q], need, hipHostMallocDefault) != hipSuccess) {
         set_error("hipHostMalloc of %zu bytes failed", need);
-        for (int z = 0; z < 2; ++z) { if (buf[z]) (void)hipHostFree(buf[z]); buf[z] = nullptr; }
+        drop();
         return FLGP_ERR_NOMEM;
       }
     bytes = need;
     return FLGP_OK;
   }
 };
-static PinnedRing g_ring;
+// The rings are handed out one per call in flight (the lock covers the hand-out only, not the multi-GB transfer): a
+// second caller gets a ring of its own, up to `hk_rings_max` (2); beyond that callers queue.  flgp_release_pinned()
+// gives the idle ones back to the system.
+static std::mutex g_ring_mu;
+static std::condition_variable g_ring_cv;
+static std::vector<PinnedRing *> g_rings;
+struct RingLease {
+  PinnedRing *r = nullptr;
+  RingLease() {
+    std::unique_lock<std::mutex> lk(g_ring_mu);
+    const size_t cap = (size_t)std::max(1, tuning("hk_rings_max", 2));
+    for (;;) {
+      for (PinnedRing *c : g_rings) if (!c->busy) { r = c; break; }
+      if (!r && g_rings.size() < cap) { r = new PinnedRing(); g_rings.push_back(r); }
+      if (r) break;
+      g_ring_cv.wait(lk);
+    }
+    r->busy = true;
+  }
+  ~RingLease() {
+    { std::lock_guard<std::mutex> lk(g_ring_mu); r->busy = false; }
+    g_ring_cv.notify_one();
+  }
+};
+// events of one call, destroyed on every way out
+struct EventSet {
+  hipEvent_t e[4] = {nullptr, nullptr, nullptr, nullptr};
+  int create() {
+    for (int q = 0; q < 4; ++q)
+      if (hipEventCreateWithFlags(&e[q], hipEventDisableTiming) != hipSuccess) { e[q] = nullptr; set_error("hipEventCreate failed"); return FLGP_ERR_HIP; }
+    return FLGP_OK;
+  }
+  ~EventSet() { for (int q = 0; q < 4; ++q) if (e[q]) (void)hipEventDestroy(e[q]); }
+};
 
 static void parallel_copy(char *dst, const char *src, size_t bytes, int nthreads, std::vector<std::thread> &pool) {
   const size_t per = (bytes / nthreads + 4095) / 4096 * 4096;
@@ -343,19 +391,18 @@ static int hk_ranges_to_host(hipStream_t st, const double *d_values, int K, doub
     FLGP_HIP(hipStreamSynchronize(st));
     return FLGP_OK;
   }
-  std::lock_guard<std::mutex> lk(g_ring.mu);
+  RingLease lease;
+  PinnedRing &ring = *lease.r;
   const size_t blkbytes = colbytes * nc;
-  FLGP_TRY(g_ring.ensure(blkbytes));
+  FLGP_TRY(ring.ensure(blkbytes));
   DevBuf dH[2], work;
   FLGP_TRY(dH[0].alloc(blkbytes)); FLGP_TRY(dH[1].alloc(blkbytes));
   FLGP_TRY(work.alloc(flgp_dev_hk_workspace(n0, nc, K, 0)));
   Stream cp;
   FLGP_TRY(cp.create());
-  hipEvent_t gemm_done[2], dma_done[2];
-  for (int q = 0; q < 2; ++q) {
-    FLGP_HIP(hipEventCreateWithFlags(&gemm_done[q], hipEventDisableTiming));
-    FLGP_HIP(hipEventCreateWithFlags(&dma_done[q], hipEventDisableTiming));
-  }
+  EventSet evs;
+  FLGP_TRY(evs.create());
+  hipEvent_t *gemm_done = evs.e, *dma_done = evs.e + 2;
   const int nthreads = std::max(1, std::min(tuning("hk_copy_threads", 8), (int)std::thread::hardware_concurrency()));
   std::vector<std::thread> copiers[2];
   auto join = [&](int q) { for (auto &th : copiers[q]) th.join(); copiers[q].clear(); };
@@ -372,24 +419,28 @@ static int hk_ranges_to_host(hipStream_t st, const double *d_values, int K, doub
       if (rc == FLGP_OK && hipEventRecord(gemm_done[q], st) != hipSuccess) rc = FLGP_ERR_HIP;
       join(q);                                   // host copy of block c-2 out of pinned buffer q
       if (rc == FLGP_OK && (hipStreamWaitEvent(cp.s, gemm_done[q], 0) != hipSuccess ||
-                            hipMemcpyAsync(g_ring.buf[q], dH[q].p, colbytes * w, hipMemcpyDeviceToHost, cp.s) != hipSuccess ||
+                            hipMemcpyAsync(ring.buf[q], dH[q].p, colbytes * w, hipMemcpyDeviceToHost, cp.s) != hipSuccess ||
                             hipEventRecord(dma_done[q], cp.s) != hipSuccess)) rc = FLGP_ERR_HIP;
     }
     if (c >= 1 && c - 1 < nblk && rc == FLGP_OK) {   // block c-1 has been enqueued: when it has landed, copy it out
       const int p = (c - 1) & 1, b0 = (c - 1) * nc, w = std::min(nc, n1 - b0);
       if (hipEventSynchronize(dma_done[p]) != hipSuccess) rc = FLGP_ERR_HIP;
-      else parallel_copy((char *)H + colbytes * b0, (const char *)g_ring.buf[p], colbytes * w, nthreads, copiers[p]);
+      else parallel_copy((char *)H + colbytes * b0, (const char *)ring.buf[p], colbytes * w, nthreads, copiers[p]);
     }
   }
   join(0); join(1);
   (void)hipStreamSynchronize(cp.s);
   (void)hipStreamSynchronize(st);
-  for (int q = 0; q < 2; ++q) { (void)hipEventDestroy(gemm_done[q]); (void)hipEventDestroy(dma_done[q]); }
   if (rc == FLGP_ERR_HIP) set_error("HIP error in the pipelined copy of H");
   return rc;
 }
 
 }  // namespace
+
+extern "C" void flgp_release_pinned(void) {
+  std::lock_guard<std::mutex> lk(g_ring_mu);
+  for (PinnedRing *c : g_rings) if (!c->busy) c->drop();
+}
 
 extern "C" int flgp_knn(const double *X, int n, int d, const double *U, int s, int r, const char *distance,
                         int *ind_knn, double *dist) {
@@ -1413,8 +1464,9 @@ extern "C" int flgp_se_spectrum_grid(const double *X_all, int n, int d, const do
     FLGP_TRY(ework.alloc(wb));
     FLGP_TRY(eig.alloc(sizeof(double) * (size_t)K));
     FLGP_TRY(V.alloc(sizeof(double) * (size_t)s * K));
-    FLGP_TRY(flgp_dev_eig_topk(ws.s, G.as<double>(), s, s, K, 0.0, eig.as<double>(), V.as<double>(), s, ework.p, wb, nullptr));
-    FLGP_TRY(flgp_dev_spectrum_usable(ws.s, eig.as<double>(), K));   // (a bandwidth that underflows a column of Z ends here, with the message)
+    int solve_info[4] = {0, 0, 0, 0};
+    FLGP_TRY(flgp_dev_eig_topk(ws.s, G.as<double>(), s, s, K, 0.0, eig.as<double>(), V.as<double>(), s, ework.p, wb, solve_info));
+    FLGP_TRY(flgp_dev_spectrum_usable_route(ws.s, eig.as<double>(), K, solve_info[2]));   // (a bandwidth that underflows a column of Z ends here, with the message)
     FLGP_TRY(vals.alloc(sizeof(double) * (size_t)K));
     FLGP_TRY(vecs.alloc(sizeof(double) * (size_t)n * K));
     FLGP_TRY(uwork.alloc(flgp_dev_u_recover_workspace(s, K)));

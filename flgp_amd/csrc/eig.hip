@@ -42,7 +42,10 @@ struct HostCtx {
   int device = -1;
   hipStream_t side = nullptr;
   hipEvent_t side_ev = nullptr, mark_ev = nullptr, wait_ev = nullptr;
+  void *pinned = nullptr;      // page-locked slots for the solve's small asynchronous read-backs (HOST_SLOT_BYTES)
 };
+constexpr int APRIORI_SLOT_DOUBLES = 512;      // 2 x APRIORI_BLOCKS (checked where the blocks are defined)
+constexpr size_t HOST_SLOT_BYTES = BSG_HOST_SLOT_BYTES + sizeof(double) * APRIORI_SLOT_DOUBLES;
 static std::mutex g_ctx_mu;
 static std::vector<HostCtx *> g_ctx_free;
 static thread_local HostCtx *g_ctx = nullptr;     // the set borrowed by the solve running on this thread
@@ -65,6 +68,7 @@ struct HostCtxLease {
       if (hipEventCreateWithFlags(&c->side_ev, hipEventDisableTiming) != hipSuccess) c->side_ev = nullptr;
       if (hipEventCreateWithFlags(&c->mark_ev, hipEventDisableTiming) != hipSuccess) c->mark_ev = nullptr;
       if (hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming) != hipSuccess) c->wait_ev = nullptr;
+      if (hipHostMalloc(&c->pinned, HOST_SLOT_BYTES, hipHostMallocDefault) != hipSuccess) c->pinned = nullptr;
     }
     g_ctx = c;
   }
@@ -1244,12 +1248,27 @@ extern "C" size_t flgp_dev_eig_workspace(int s, int K) {
   return eig_workspace_bytes(s, K);
 }
 
+static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, double tol, double *d_values, double *dV,
+                         int ldv, void *d_work, size_t work_bytes, int *info);
+
 extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s, int K, double tol,
                                  double *d_values, double *dV, int ldv, void *d_work, size_t work_bytes,
                                  int *info) {
-  hipStream_t st = (hipStream_t)stream;
   FLGP_REQUIRE(s >= 1 && ldg >= s && ldv >= s, "eig: bad shape");
-  HostCtxLease lease;   // second stream + events for this solve
+  HostCtxLease lease;   // second stream + events + pinned read-back slots for this solve
+  const int rc = eig_topk_impl(stream, dG, ldg, s, K, tol, d_values, dV, ldv, d_work, work_bytes, info);
+  if (rc != FLGP_OK) {
+    // An early return may leave work of this solve on either stream (the Lanczos steps on the side stream, copies into
+    // the context's host slots): it must not outlive the workspace the caller is about to free, nor the lease.
+    if (g_ctx && g_ctx->side) (void)hipStreamSynchronize(g_ctx->side);
+    (void)hipStreamSynchronize((hipStream_t)stream);
+  }
+  return rc;
+}
+
+static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, double tol, double *d_values, double *dV,
+                         int ldv, void *d_work, size_t work_bytes, int *info) {
+  hipStream_t st = (hipStream_t)stream;
   if (K < 0) K = s;
   FLGP_REQUIRE(K >= 1 && K <= s, "eig: need 1 <= K <= s (K=%d, s=%d)", K, s);
   FLGP_REQUIRE(work_bytes >= eig_workspace_bytes(s, K), "eig: workspace too small");
@@ -1281,6 +1300,7 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   BsG bs;
   if (!dense && s >= std::max(1024, tuning("eig_bs_min_s", 1536)) && tuning("eig_blocksparse", 1)) {
     bsg_carve(bs, p, s, b);
+    if (g_ctx && g_ctx->pinned) bsg_host_slots(bs, g_ctx->pinned);
     FLGP_TRY(bsg_setup(st, dG, ldg, s, bs, g_ctx ? g_ctx->side : nullptr, g_ctx ? g_ctx->side_ev : nullptr));
   }
 
@@ -1550,7 +1570,9 @@ extern "C" int flgp_dev_eig_topk(void *stream, const double *dG, int ldg, int s,
   // first Rayleigh-Ritz step (two Jacobi sweeps, two rotations, a host round trip) is saved.
   const int skip_rr_n = tuning("eig_skip_rr0", 1) ? std::max(1, tuning("eig_skip_rr_n", 1)) : 0;   // iterations without Rayleigh-Ritz
   const bool skip_rr0 = skip_rr_n > 0;
-  double h_apriori[2 * APRIORI_BLOCKS];
+  static_assert(2 * APRIORI_BLOCKS <= APRIORI_SLOT_DOUBLES, "the pinned slot of the a-priori bounds");
+  double h_apriori_own[2 * APRIORI_BLOCKS];
+  double *h_apriori = (g_ctx && g_ctx->pinned) ? (double *)((char *)g_ctx->pinned + BSG_HOST_SLOT_BYTES) : h_apriori_own;
   if (skip_rr0 && !bs.built) {
     hipLaunchKernelGGL(apriori_bounds_kernel, dim3(APRIORI_BLOCKS), dim3(256), 0, st, dG, ldg, s, w.apriori);
     FLGP_TRY(check_launch("apriori_bounds_kernel"));

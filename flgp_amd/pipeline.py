@@ -149,12 +149,15 @@ class HipStages:
         return eig, V, dict(outer_iterations=info[0], g_products=info[1], dense=bool(info[2]),
                             newton_schulz_orths=info[3] // 1000, jacobi_orths=info[3] % 1000)
 
-    def u_recover(self, ell_idx, ell_val, V, eig, scale, root):
+    def u_recover(self, ell_idx, ell_val, V, eig, scale, root, dense=None):
+        """dense: did the full decomposition deliver `eig` (eig_topk's info["dense"])?  Default: K == s."""
         n, r = ell_idx.shape
         K, s = V.shape
+        if dense is None:
+            dense = K >= s
         values = self.empty((K,)); vectors = self.empty((K, max(n, 1)))
         work = self.empty((self.L.flgp_dev_u_recover_workspace(s, K) // 8 + 1,))
-        _lib.check(self.L.flgp_dev_spectrum_usable(self._st(), eig.data_ptr(), K))      # sigma_K > 0, or the reason why not
+        _lib.check(self.L.flgp_dev_spectrum_usable_route(self._st(), eig.data_ptr(), K, int(bool(dense))))   # sigma_K resolved, or the reason why not
         _lib.check(self.L.flgp_dev_u_recover(self._st(), ell_idx.data_ptr(), ell_val.data_ptr(), n, r, V.data_ptr(), s, s,
                                              eig.data_ptr(), K, float(scale), int(bool(root)), vectors.data_ptr(), max(n, 1),
                                              values.data_ptr(), work.data_ptr()))
@@ -342,7 +345,7 @@ class HeatKernelPath:
         K = s if cfg.K < 0 else cfg.K
         eig, V, info = S.eig_topk(G, K)
         tm.mark("eig")
-        values, vectors = S.u_recover(ell_idx, ell_val, V, eig, math.sqrt(float(n_global)), cfg.root)
+        values, vectors = S.u_recover(ell_idx, ell_val, V, eig, math.sqrt(float(n_global)), cfg.root, dense=info.get("dense"))
         tm.mark("u_recover")
         # k7: heat kernel against the training block V[0:m]
         m = cfg.m

@@ -73,7 +73,7 @@ class OracleStages:
         V = V * np.sign(V[np.abs(V).argmax(0), np.arange(K)])[None, :]   # deterministic signs across ranks
         return torch.from_numpy(w), _t_cm(V), dict(outer_iterations=0, g_products=0, dense=True)
 
-    def u_recover(self, ell_idx, ell_val, V, eig, scale, root):
+    def u_recover(self, ell_idx, ell_val, V, eig, scale, root, dense=None):
         K, s = V.shape
         sig = np.sqrt(np.maximum(eig.numpy(), 0.0))
         n = ell_idx.shape[0]

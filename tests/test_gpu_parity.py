@@ -990,6 +990,17 @@ def test_unusable_spectrum_is_refused_on_every_path(stages):
     ei = torch.zeros((8, r), dtype=torch.int32, device="cuda:0"); ev = torch.ones((8, r), dtype=torch.float64, device="cuda:0")
     with pytest.raises(Exception):
         stages.u_recover(ei, ev, V, eig, 1.0, True)
+    # The floor follows what the route that computed the eigenvalues resolves: 1e-10 of the top one for the
+    # block solver (residuals 5e-11 lambda_1), 1e-13 for the full decomposition.
+    import ctypes
+    L = _lib.lib()
+    st = torch.cuda.current_stream().cuda_stream
+    for low, full, ok in ((1e-9, 0, True), (1e-11, 0, False), (1e-11, 1, True), (1e-14, 1, False), (0.0, 1, False)):
+        e3 = torch.tensor([1.0, 0.5, low], dtype=torch.float64, device="cuda:0")
+        rc = L.flgp_dev_spectrum_usable_route(st, e3.data_ptr(), 3, full)
+        assert (rc == 0) == ok, (low, full, rc)
+        if not ok: assert rc == -5 and b"null space" in L.flgp_last_error()
+    assert L.flgp_dev_spectrum_usable(st, torch.tensor([1.0, 1e-11], dtype=torch.float64, device="cuda:0").data_ptr(), 2) == -5
 
 
 def test_pipeline_matches_host_entry_points(oracle, stages):
@@ -1025,6 +1036,23 @@ def test_pipelined_copy_of_H_is_the_same_matrix(oracle):
         L.flgp_set_tuning(b"hk_block_mb", 512)
     np.testing.assert_array_equal(H1, H0)
     np.testing.assert_array_equal(G1, G0)
+    # Two callers at once take a staging ring each (the lock covers the hand-out, not the transfer); the idle rings go
+    # back to the system on request and the next call simply pins again.
+    import threading
+    out = [None, None]
+    def call(q):
+        out[q] = api.HK_from_spectrum_cpp(ep, 40, 3.0, np.arange(100, 20000), np.arange(5, 305))
+    try:
+        L.flgp_set_tuning(b"hk_block_mb", 1)
+        th = [threading.Thread(target=call, args=(q,)) for q in range(2)]
+        for t_ in th: t_.start()
+        for t_ in th: t_.join()
+        L.flgp_release_pinned()
+        G2 = api.HK_from_spectrum_cpp(ep, 40, 3.0, np.arange(100, 20000), np.arange(5, 305))
+    finally:
+        L.flgp_set_tuning(b"hk_block_mb", 512)
+    for g in (out[0], out[1], G2):
+        np.testing.assert_array_equal(g, G0)
 
 
 # ------------------------------------------------------------------------------ full size (BASELINE configs[2])
