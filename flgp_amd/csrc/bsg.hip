@@ -852,7 +852,11 @@ void bsg_carve(BsG &g, char *&p, int s, int b) {
   int *lab2 = (int *)take(sizeof(int) * (size_t)s);
   g.perm = (int *)take(sizeof(int) * (size_t)s); g.iperm = (int *)take(sizeof(int) * (size_t)s);
   g.rcnt = lab2;   // the second label buffer is free again once the ordering is done; (s + 1 ints are not needed: s suffice)
-  g.E0 = (double *)take(sizeof(double) * (size_t)s * BSG_SEEDS); g.E1 = (double *)take(sizeof(double) * (size_t)s * BSG_SEEDS);
+  // (rows rounded up to whole chunks of BSG_CW_ROWS: E0 later holds one 64 x 64 table per chunk, and with the exact size the
+  //  last chunk's table ran 28 KB into E1 at s = 5000 -- the rows other workgroups of the same launch were still reading: the
+  //  cluster weights, hence the ordering, depended on timing until round 3 made the Lanczos steps truly concurrent and it showed)
+  const size_t rows_up = ((size_t)s + BSG_CW_ROWS - 1) / BSG_CW_ROWS * BSG_CW_ROWS;
+  g.E0 = (double *)take(sizeof(double) * rows_up * BSG_SEEDS); g.E1 = (double *)take(sizeof(double) * rows_up * BSG_SEEDS);
   g.cnt = (int *)take(sizeof(int) * nt * ng); g.blkpos = (int *)take(sizeof(int) * nt * ng);
   g.nk = (int *)take(sizeof(int) * (nt + 1)); g.off = (int *)take(sizeof(int) * (nt + 1));
   g.order = (int *)take(sizeof(int) * (nt + 1)); (void)take(sizeof(int) * (nt + 1));
