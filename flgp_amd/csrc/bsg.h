@@ -65,11 +65,14 @@ struct BsG {
   int *h_meta = h_meta_own;       // host copy of meta
   int launches = 0;               // products issued
   std::vector<int> h_perm;        // source of an asynchronous upload: lives as long as the struct
+  void *h_big = nullptr;          // caller-owned pinned memory for the set-up's larger exchange (bsg_host_slots), or null
+  size_t h_big_bytes = 0;
 };
 
 constexpr size_t BSG_HOST_SLOT_BYTES = sizeof(double) * (2 + 64) + sizeof(int) * BSG_META;
-// point the read-back copies at caller-owned (pinned) host memory of BSG_HOST_SLOT_BYTES bytes
-void bsg_host_slots(BsG &g, void *slots);
+// point the read-back copies at caller-owned (pinned) host memory of BSG_HOST_SLOT_BYTES bytes; `big` (optional, big_bytes
+// of pinned memory) takes the set-up's one larger exchange with the host: cluster weights + labels down, permutation up
+void bsg_host_slots(BsG &g, void *slots, void *big = nullptr, size_t big_bytes = 0);
 size_t bsg_workspace_bytes(int s, int b);
 // carve the members out of a workspace (advances p)
 void bsg_carve(BsG &g, char *&p, int s, int b);

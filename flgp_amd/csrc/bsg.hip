@@ -824,7 +824,8 @@ static size_t bsg_pack_cap(int s) {
   return nt * ng / 2 + 1;
 }
 
-void bsg_host_slots(BsG &g, void *slots) {
+void bsg_host_slots(BsG &g, void *slots, void *big, size_t big_bytes) {
+  g.h_big = big; g.h_big_bytes = big_bytes;
   double *d = (double *)slots;
   g.h_bounds = d; g.h_ab = d + 2; g.h_meta = (int *)(d + 2 + 64);
   for (int q = 0; q < 2 + 64; ++q) d[q] = 0.0;
@@ -925,7 +926,11 @@ int bsg_setup(hipStream_t st, const double *dG, int ldg, int s, BsG &g, hipStrea
   FLGP_TRY(check_launch("bsg ordering"));
   const int p = BSG_SEEDS;
   // one copy for the three things the host needs: C (p x p doubles), meta, labels are adjacent in the workspace
-  std::vector<double> xfer((size_t)p * p + (BSG_META * sizeof(int) + sizeof(int) * (size_t)s + 7) / 8 + 1);
+  const size_t xfer_doubles = (size_t)p * p + (BSG_META * sizeof(int) + sizeof(int) * (size_t)s + 7) / 8 + 1;
+  const bool big_ok = g.h_big && g.h_big_bytes >= sizeof(double) * xfer_doubles + sizeof(int) * (size_t)s;
+  std::vector<double> xfer_own(big_ok ? 0 : xfer_doubles);
+  double *xfer_p = big_ok ? (double *)g.h_big : xfer_own.data();
+  struct { double *p; double *data() const { return p; } } xfer{xfer_p};
   FLGP_HIP(hipMemcpyAsync(xfer.data(), g.Cw, sizeof(double) * p * p + sizeof(int) * (BSG_META + (size_t)s), hipMemcpyDeviceToHost, st));
   FLGP_HIP(stream_wait(st));
   const double *C = xfer.data();
@@ -963,7 +968,13 @@ int bsg_setup(hipStream_t st, const double *dG, int ldg, int s, BsG &g, hipStrea
   }
   for (int q = 0; q <= p; ++q) start[q + 1] += start[q];
   for (int i = 0; i < s; ++i) perm[start[rank[lab[i]]]++] = i;   // stable counting sort by cluster rank
-  FLGP_HIP(hipMemcpyAsync(g.perm, perm.data(), sizeof(int) * s, hipMemcpyHostToDevice, st));
+  const int *perm_src = perm.data();
+  if (big_ok) {                                  // upload from the pinned area (behind the part the download used)
+    int *pp = (int *)((char *)g.h_big + sizeof(double) * xfer_doubles);
+    memcpy(pp, perm.data(), sizeof(int) * (size_t)s);
+    perm_src = pp;
+  }
+  FLGP_HIP(hipMemcpyAsync(g.perm, perm_src, sizeof(int) * s, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(bsg_iperm_kernel, dim3(ceil_div(s, 256)), dim3(256), 0, st, g.perm, s, g.iperm);
   hipLaunchKernelGGL(bsg_count_kernel, dim3(g.ntile), dim3(256), sizeof(int) * g.nstage, st, g.gptr, g.gcol, g.perm, g.iperm, s,
                      g.nstage, g.cnt);

@@ -43,9 +43,14 @@ struct HostCtx {
   hipStream_t side = nullptr;
   hipEvent_t side_ev = nullptr, mark_ev = nullptr, wait_ev = nullptr;
   void *pinned = nullptr;      // page-locked slots for the solve's small asynchronous read-backs (HOST_SLOT_BYTES)
+  void *pinned_dev = nullptr;  // the same memory as the device addresses it (null: kernels cannot write it, copies are used)
 };
+constexpr int DIST_SLOT_DOUBLES = 64;          // partial sums dist_to_identity_kernel writes straight into host memory
+constexpr int RT_SLOT_DOUBLES = 2 * 4096;      // residuals + sorted Ritz values of a Rayleigh-Ritz step (2 b doubles), likewise
 constexpr int APRIORI_SLOT_DOUBLES = 512;      // 2 x APRIORI_BLOCKS (checked where the blocks are defined)
-constexpr size_t HOST_SLOT_BYTES = BSG_HOST_SLOT_BYTES + sizeof(double) * APRIORI_SLOT_DOUBLES;
+constexpr size_t HOST_SMALL_BYTES = BSG_HOST_SLOT_BYTES + sizeof(double) * (APRIORI_SLOT_DOUBLES + DIST_SLOT_DOUBLES + RT_SLOT_DOUBLES);
+constexpr size_t HOST_BIG_BYTES = 512 << 10;   // the block-sparse set-up's exchange: 32 KB of cluster weights + 8 bytes per anchor
+constexpr size_t HOST_SLOT_BYTES = HOST_SMALL_BYTES + HOST_BIG_BYTES;
 static std::mutex g_ctx_mu;
 static std::vector<HostCtx *> g_ctx_free;
 static thread_local HostCtx *g_ctx = nullptr;     // the set borrowed by the solve running on this thread
@@ -68,7 +73,14 @@ struct HostCtxLease {
       if (hipEventCreateWithFlags(&c->side_ev, hipEventDisableTiming) != hipSuccess) c->side_ev = nullptr;
       if (hipEventCreateWithFlags(&c->mark_ev, hipEventDisableTiming) != hipSuccess) c->mark_ev = nullptr;
       if (hipEventCreateWithFlags(&c->wait_ev, hipEventDisableTiming) != hipSuccess) c->wait_ev = nullptr;
-      if (hipHostMalloc(&c->pinned, HOST_SLOT_BYTES, hipHostMallocDefault) != hipSuccess) c->pinned = nullptr;
+      // coherent (fine-grained) and mapped: kernels write a step's verdict straight into it, the host reads it behind the
+      // event that follows the kernel -- no copy launch, no staging (a D2H copy of 256 bytes into pageable memory was a blit
+      // kernel plus a host memcpy per question, ~45 questions per solve)
+      if (hipHostMalloc(&c->pinned, HOST_SLOT_BYTES, hipHostMallocMapped | hipHostMallocCoherent) != hipSuccess) {
+        (void)hipGetLastError();
+        if (hipHostMalloc(&c->pinned, HOST_SLOT_BYTES, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); c->pinned = nullptr; }
+      }
+      if (c->pinned && hipHostGetDevicePointer(&c->pinned_dev, c->pinned, 0) != hipSuccess) { (void)hipGetLastError(); c->pinned_dev = nullptr; }
     }
     g_ctx = c;
   }
@@ -911,7 +923,7 @@ __global__ __launch_bounds__(256) void dist_to_identity_kernel(const double *__r
     if ((int)threadIdx.x < off) red[threadIdx.x] += red[threadIdx.x + off];
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[blockIdx.x] = red[0];
+  if (threadIdx.x == 0) { out[blockIdx.x] = red[0]; __threadfence_system(); }   // (out may be host memory)
 }
 
 __global__ void set_identity_kernel(double *__restrict__ M, int b) {
@@ -929,8 +941,9 @@ __global__ void row_scale_kernel(const double *__restrict__ Z, int b, const doub
 }
 
 // res[j] = | Z(:,j) - theta_j Q(:,j) |_2 , j < K ; also column norms of Q when Z == nullptr
+// (host: optional host-visible copy of what the step's one round trip asks for -- [0, gridDim.x) the residuals, [b, 2b) theta)
 __global__ void resid_kernel(const double *__restrict__ Z, const double *__restrict__ Q, int s, int ld,
-                             const double *__restrict__ theta, double *__restrict__ res) {
+                             const double *__restrict__ theta, double *__restrict__ res, double *__restrict__ host, int b) {
   const int j = blockIdx.x;
   __shared__ double red[256];
   double acc = 0.0;
@@ -946,6 +959,11 @@ __global__ void resid_kernel(const double *__restrict__ Z, const double *__restr
     __syncthreads();
   }
   if (threadIdx.x == 0) res[j] = __builtin_sqrt(red[0]);
+  if (host) {
+    if (threadIdx.x == 0) host[j] = __builtin_sqrt(red[0]);
+    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < b; q += gridDim.x * blockDim.x) host[b + q] = theta[q];
+    __threadfence_system();
+  }
 }
 
 // A-priori spectrum bounds of the symmetric PSD matrix G, for the one filter that runs before any Rayleigh-Ritz step:
@@ -1302,7 +1320,8 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
   BsG bs;
   if (!dense && s >= std::max(1024, tuning("eig_bs_min_s", 1536)) && tuning("eig_blocksparse", 1)) {
     bsg_carve(bs, p, s, b);
-    if (g_ctx && g_ctx->pinned && tuning("eig_pinned_slots", 1)) bsg_host_slots(bs, g_ctx->pinned);
+    if (g_ctx && g_ctx->pinned && tuning("eig_pinned_slots", 1))
+      bsg_host_slots(bs, g_ctx->pinned, (char *)g_ctx->pinned + HOST_SMALL_BYTES, HOST_BIG_BYTES);
     FLGP_TRY(bsg_setup(st, dG, ldg, s, bs, g_ctx ? g_ctx->side : nullptr, g_ctx ? g_ctx->side_ev : nullptr));
   }
 
@@ -1386,11 +1405,27 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
     FLGP_TRY(small_gemm(A0, B0, 1.0, 0.0, nullptr, out0));
     return small_gemm(A1, B1, 1.0, 0.0, nullptr, out1);
   };
+  // host-visible result slots (HostCtx::pinned): [bsg | a-priori bounds | dist partials | residuals + Ritz values]
+  static_assert(DIST_BLOCKS <= DIST_SLOT_DOUBLES, "slot of the distance partials");
+  const bool host_slots = g_ctx && g_ctx->pinned && g_ctx->pinned_dev && tuning("eig_host_slots", 1);
+  const size_t dist_off = BSG_HOST_SLOT_BYTES + sizeof(double) * APRIORI_SLOT_DOUBLES;
+  const size_t rt_off = dist_off + sizeof(double) * DIST_SLOT_DOUBLES;
+  double *dist_h = host_slots ? (double *)((char *)g_ctx->pinned + dist_off) : nullptr;
+  double *dist_d = host_slots ? (double *)((char *)g_ctx->pinned_dev + dist_off) : nullptr;
+  double *rt_h = (host_slots && 2 * b <= RT_SLOT_DOUBLES) ? (double *)((char *)g_ctx->pinned + rt_off) : nullptr;
+  double *rt_d = rt_h ? (double *)((char *)g_ctx->pinned_dev + rt_off) : nullptr;
   auto dist_to_identity = [&](const double *M, double *out) -> int {
-    double part[DIST_BLOCKS];
-    hipLaunchKernelGGL(dist_to_identity_kernel, dim3(DIST_BLOCKS), dim3(256), 0, st, M, b, w.res);
-    FLGP_TRY(check_launch("dist_to_identity_kernel"));
-    FLGP_HIP(hipMemcpyAsync(part, w.res, sizeof(double) * DIST_BLOCKS, hipMemcpyDeviceToHost, st));
+    double part_own[DIST_BLOCKS];
+    const double *part = part_own;
+    if (dist_d) {
+      hipLaunchKernelGGL(dist_to_identity_kernel, dim3(DIST_BLOCKS), dim3(256), 0, st, M, b, dist_d);
+      FLGP_TRY(check_launch("dist_to_identity_kernel"));
+      part = dist_h;
+    } else {
+      hipLaunchKernelGGL(dist_to_identity_kernel, dim3(DIST_BLOCKS), dim3(256), 0, st, M, b, w.res);
+      FLGP_TRY(check_launch("dist_to_identity_kernel"));
+      FLGP_HIP(hipMemcpyAsync(part_own, w.res, sizeof(double) * DIST_BLOCKS, hipMemcpyDeviceToHost, st));
+    }
     FLGP_HIP(stream_wait(st));
     double sum = 0.0;
     for (int q = 0; q < DIST_BLOCKS; ++q) sum += part[q];
@@ -1429,10 +1464,11 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
         // the last M must be the identity to rounding.  Its check is a host round trip: the rotation it would
         // allow is enqueued behind the measurement first (a failed check just overwrites Qout later), so the
         // GPU multiplies while the host reads the verdict
-        double part[DIST_BLOCKS];
-        hipLaunchKernelGGL(dist_to_identity_kernel, dim3(DIST_BLOCKS), dim3(256), 0, st, Mm, b, w.res);
+        double part_own[DIST_BLOCKS];
+        const double *part = dist_d ? dist_h : part_own;
+        hipLaunchKernelGGL(dist_to_identity_kernel, dim3(DIST_BLOCKS), dim3(256), 0, st, Mm, b, dist_d ? dist_d : w.res);
         FLGP_TRY(check_launch("dist_to_identity_kernel"));
-        FLGP_HIP(hipMemcpyAsync(part, w.res, sizeof(double) * DIST_BLOCKS, hipMemcpyDeviceToHost, st));
+        if (!dist_d) FLGP_HIP(hipMemcpyAsync(part_own, w.res, sizeof(double) * DIST_BLOCKS, hipMemcpyDeviceToHost, st));
         FLGP_HIP(stream_mark(st));
         // Zc may live in JV or X2; the rotation needs diag(dinv) Z in W (Mm's buffer: read by the kernel above first)
         hipLaunchKernelGGL(row_scale_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, Zc, b, w.dinv, w.W);
@@ -1709,13 +1745,14 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
   // the ONE host round trip of a Rayleigh-Ritz step: brings the residuals and the sorted Ritz values over together
   std::vector<double> rt(2 * (size_t)b);
   auto residuals = [&](const double *A, const double *B, double *rmax_out) -> int {
-    hipLaunchKernelGGL(resid_kernel, dim3(K), dim3(256), 0, st, B, A, s, s, w.theta, w.res);
+    hipLaunchKernelGGL(resid_kernel, dim3(K), dim3(256), 0, st, B, A, s, s, w.theta, w.res, rt_d, b);
     FLGP_TRY(check_launch("resid_kernel"));
-    FLGP_HIP(hipMemcpyAsync(rt.data(), w.res, sizeof(double) * 2 * b, hipMemcpyDeviceToHost, st));
+    const double *rtp = rt_h;
+    if (!rt_d) { FLGP_HIP(hipMemcpyAsync(rt.data(), w.res, sizeof(double) * 2 * b, hipMemcpyDeviceToHost, st)); rtp = rt.data(); }
     FLGP_HIP(stream_wait(st));
     double rmax = 0.0;
-    for (int j = 0; j < K; ++j) { res[j] = rt[j]; rmax = std::max(rmax, res[j]); }
-    for (int j = 0; j < b; ++j) theta[j] = rt[b + j];
+    for (int j = 0; j < K; ++j) { res[j] = rtp[j]; rmax = std::max(rmax, res[j]); }
+    for (int j = 0; j < b; ++j) theta[j] = rtp[b + j];
     *rmax_out = rmax;
     return FLGP_OK;
   };
