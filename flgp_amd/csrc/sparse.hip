@@ -148,11 +148,12 @@ __global__ __launch_bounds__(64) void colsum_chunk_kernel(const int *__restrict_
       const unsigned long long bal = __ballot(bit);
       m &= bit ? bal : ~bal;
     }
-    const int rank = act ? __popcll(m & lt) : 0;
-    int maxrank = rank;
-    for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(maxrank, off, 64); maxrank = o > maxrank ? o : maxrank; }
-    for (int k = 0; k <= maxrank; ++k)
-      if (act && rank == k)
+    const int rank = act ? __popcll(m & lt) : -1;
+    // pass k adds the lanes of rank k; the ranks of a column's lanes are 0, 1, 2, ... without gaps, so the first k that
+    // nobody holds ends the step (a ballot per pass; the wave-wide maximum by six dependent shuffles that stood here was
+    // most of the step: ~700 of its ~1200 cycles)
+    for (int k = 0; __ballot(rank == k) != 0ull; ++k)
+      if (rank == k)
         __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)&bins[col], v);
     col = coln; v = vn;
   }
