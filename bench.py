@@ -151,12 +151,15 @@ def main():
         try:
             import torch.distributed as dist
             idbuf = (ctypes.c_char * 128)()
-            if rank == 0:
-                _lib.check(L.flgp_comm_rccl_unique_id(idbuf))
-            idt = torch.frombuffer(bytearray(bytes(idbuf)), dtype=torch.uint8).to(device)
+            id_ok = 1
+            if rank == 0 and L.flgp_comm_rccl_unique_id(idbuf) != 0:
+                id_ok = 0            # (say so in the broadcast: the other ranks are waiting in it)
+            idt = torch.frombuffer(bytearray(bytes(idbuf) + bytes([id_ok])), dtype=torch.uint8).to(device)
             dist.broadcast(idt, src=0)
             raw = bytes(idt.cpu().numpy().tobytes())
-            cbuf = (ctypes.c_char * 128).from_buffer_copy(raw)
+            if raw[128] != 1:
+                raise RuntimeError("rank 0 could not create an RCCL id: " + L.flgp_last_error().decode("utf-8", "replace"))
+            cbuf = (ctypes.c_char * 128).from_buffer_copy(raw[:128])
             out_c = (ctypes.c_void_p * 1)()
             _lib.check(L.flgp_comm_rccl_init_rank(world, rank, cbuf, out_c))
             comm = out_c[0]

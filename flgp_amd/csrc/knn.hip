@@ -363,20 +363,24 @@ __device__ __forceinline__ void screen_sweep(const uint4 *__restrict__ panel, co
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       if constexpr (PASS == 0) {
+        // (plain fmaxf: the `+ 0.0f` that stood here until round 3, to hand the compiler a canonical float, had become an
+        //  extra v_add per product with this compiler -- 64 of the 128 VALU instructions of a pair of tiles; without it the
+        //  maxima fuse into v_max3_f32 and nothing is added)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) g[t][i] = fmaxf(g[t][i], acc[t][i] + 0.0f);   // + 0: a float the compiler knows canonical
+        for (int i = 0; i < 16; ++i) g[t][i] = fmaxf(g[t][i], acc[t][i]);
       } else {
         char *qp = (char *)(q + kh * PB + w * 64 + t * 32 + col);
 #pragma unroll
         for (int g4 = 0; g4 < 4; ++g4) {
-          int iv[4];
-#pragma unroll
-          for (int i = 0; i < 4; ++i) iv[i] = __float_as_int(acc[t][4 * g4 + i] - tau[t]);
-          const int m = max(max(max(iv[0], iv[1]), iv[2]), iv[3]);
-          if (__ballot(m >= 0)) {
+          // a >= tau decided on the group's maximum first (two max instructions and a compare for four products; the
+          // difference a - tau per product, as it stood until round 3, was four more -- and a - tau >= 0 iff a >= tau:
+          // a difference of two floats is zero only if they are equal, and rounding keeps its sign).  No NaNs here: points
+          // the screen has no say about carry tau = +inf and zeroed operands, the panel is finite.
+          const float m = fmaxf(fmaxf(fmaxf(acc[t][4 * g4], acc[t][4 * g4 + 1]), acc[t][4 * g4 + 2]), acc[t][4 * g4 + 3]);   // v_max3 + v_max
+          if (__ballot(m >= tau[t])) {
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
-              if (iv[i] >= 0) {       // cnt counts in bytes of queue stride; past QC entries: overwritten, and counted
+              if (acc[t][4 * g4 + i] >= tau[t]) {       // cnt counts in bytes of queue stride; past QC entries: overwritten, and counted
                 *(unsigned short *)(qp + (cnt[t] & ((QC - 1) * 4 * PB))) = (unsigned short)(j0 + 8 * g4 + i);
                 cnt[t] += 4 * PB;
               }
