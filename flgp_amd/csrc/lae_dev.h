@@ -38,6 +38,23 @@ struct SortNetHolder {
   static constexpr SortNet<N> net = SortNet<N>();
 };
 
+// The comparators of the network with their indices as CONSTANT EXPRESSIONS (template recursion).  Read in an unrolled loop
+// from the constexpr table they were not folded: the compiler kept the table in memory and indexed the register array
+// dynamically -- s_set_gpr_idx_on / v_mov / v_mov / s_set_gpr_idx_off around every operand, 124 times per projection, half
+// of the instructions of an LAE iteration (round 3, found in the ISA).
+template <int N, int C>
+__device__ __forceinline__ void sort_net_apply(double (&vd)[N]) {
+  constexpr SortNet<N> net = SortNet<N>();
+  if constexpr (C < net.count) {
+    constexpr int ia = net.a[C], ib = net.b[C];
+    const double hi = __builtin_fmax(vd[ia], vd[ib]);
+    const double lo = __builtin_fmin(vd[ia], vd[ib]);
+    vd[ia] = hi;
+    vd[ib] = lo;
+    sort_net_apply<N, C + 1>(vd);
+  }
+}
+
 // x / J for a small integer constant J, correctly rounded: q0 = RN(x * RN(1/J)) is within one ulp,
 // r = x - J q0 is exact in an FMA, and RN(q0 + r * RN(1/J)) is the correctly rounded quotient
 // (Markstein's theorem) as long as nothing overflows and the quotient is normal -- the caller checks the
@@ -78,15 +95,7 @@ __device__ __forceinline__ void v_to_z_dev(const double *vv, double *zz, int r) 
 #pragma unroll
   for (int a = 0; a < RR; ++a) vd[a] = (a < r) ? vv[a] : -__builtin_inf();
   // descending sort (any correct sort gives the same array of values)
-  constexpr const SortNet<RR> &net = SortNetHolder<RR>::net;
-#pragma unroll
-  for (int c = 0; c < net.count; ++c) {
-    const int ia = net.a[c], ib = net.b[c];
-    const double hi = __builtin_fmax(vd[ia], vd[ib]);
-    const double lo = __builtin_fmin(vd[ia], vd[ib]);
-    vd[ia] = hi;
-    vd[ib] = lo;
-  }
+  sort_net_apply<RR, 0>(vd);
   double theta = 0.0;
   if constexpr (R > 0) {
     // |cumsum_j - 1| is 0 or >= 2^-53 (doubles next to 1), so the quotients are never subnormal; the
