@@ -123,21 +123,17 @@ __global__ __launch_bounds__(64) void csc_scatter_kernel(const int *__restrict__
 // needs; the LDS unit executes a wave's instructions in order, so pass k+1 sees pass k.
 constexpr int COLSUM_CHUNK = 1024;     // rows; FLGP_COLSUM_CHUNK of the oracle
 
-constexpr int COLSUM_OWN = 512;        // buckets of the lane arbitration (column & 511): 2 KB beside the s sums (s <= 20000 still fits 160 KB)
-
 __global__ __launch_bounds__(64) void colsum_chunk_kernel(const int *__restrict__ ell_idx, const double *__restrict__ val,
                                                           int n, int r, int s, int nbits, double *__restrict__ part) {
   extern __shared__ double bins[];
-  unsigned *own = (unsigned *)(bins + s);        // [COLSUM_OWN]
   const int lane = threadIdx.x;
-  (void)nbits;
   for (int j = lane; j < s; j += 64) bins[j] = 0.0;
-  for (int j = lane; j < COLSUM_OWN; j += 64) own[j] = 0xffffffffu;
   __syncthreads();
   const long i0 = (long)blockIdx.x * COLSUM_CHUNK;
   const long i1 = (i0 + COLSUM_CHUNK < n) ? i0 + COLSUM_CHUNK : n;
   const long e0 = i0 * r, e1 = i1 * r;
-  // the next step's entries are loaded while this step's are added
+  const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  // the next step's entries are loaded while this step's are ranked and added
   long e = e0 + lane;
   int col = (e < e1) ? ell_idx[e] : 0;
   double v = (e < e1) ? val[e] : 0.0;
@@ -145,22 +141,20 @@ __global__ __launch_bounds__(64) void colsum_chunk_kernel(const int *__restrict_
     const long en = eb + 64 + lane;
     const int coln = (en < e1) ? ell_idx[en] : 0;
     const double vn = (en < e1) ? val[en] : 0.0;
-    // Lanes of one step that hit the same column must add in lane (= entry) order.  Arbitration instead of ranking (round 3;
-    // the ranks took a ballot per bit of the column index, ~160 instructions a step): every pending lane bids its number for
-    // its column's bucket with an LDS atomic minimum, the lowest bidder of a bucket adds and leaves, the others bid again.
-    // A column's lanes therefore add in ascending lane order, one LDS instruction after the other (the LDS unit executes a
-    // wave's instructions in order); two columns in one bucket only cost a pass.
-    bool pending = eb + lane < e1;
-    const int h = col & (COLSUM_OWN - 1);
-    while (__ballot(pending) != 0ull) {
-      if (pending) atomicMin(&own[h], (unsigned)lane);
-      const unsigned w = pending ? own[h] : 0xffffffffu;
-      if (pending && w == (unsigned)lane) {
-        __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)&bins[col], v);
-        own[h] = 0xffffffffu;
-        pending = false;
-      }
+    const bool act = eb + lane < e1;
+    unsigned long long m = __ballot(act);
+    for (int b = 0; b < nbits; ++b) {
+      const bool bit = (col >> b) & 1;
+      const unsigned long long bal = __ballot(bit);
+      m &= bit ? bal : ~bal;
     }
+    const int rank = act ? __popcll(m & lt) : -1;
+    // pass k adds the lanes of rank k; the ranks of a column's lanes are 0, 1, 2, ... without gaps, so the first k that
+    // nobody holds ends the step (a ballot per pass; the wave-wide maximum by six dependent shuffles that stood here was
+    // most of the step: ~700 of its ~1200 cycles)
+    for (int k = 0; __ballot(rank == k) != 0ull; ++k)
+      if (rank == k)
+        __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)&bins[col], v);
     col = coln; v = vn;
   }
   __syncthreads();
@@ -535,7 +529,7 @@ extern "C" int flgp_dev_colsum(void *stream, const int *d_ell_idx, const double 
   const int nchunks = ceil_div(n > 0 ? n : 1, COLSUM_CHUNK);
   int nbits = 1;
   while ((1 << nbits) < s) ++nbits;
-  const size_t lds = sizeof(double) * (size_t)s + sizeof(unsigned) * COLSUM_OWN;
+  const size_t lds = sizeof(double) * (size_t)s;
   if (lds > 48 * 1024)
     FLGP_HIP(hipFuncSetAttribute((const void *)colsum_chunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   ProfScope ps("colsum_kernel", st, 12.0 * (double)n * r);
