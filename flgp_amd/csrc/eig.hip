@@ -436,18 +436,20 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
   __syncthreads();
   jac_stamp(tr, 2);
   // ---- two-sided cyclic Jacobi on Gm, rotations accumulated in Wm.
-  // Per round: NP leader lanes turn (Gm_pp, Gm_qq, Gm_pq) into rotation coefficients, then every
-  // thread rebuilds ONE element of J^T Gm J and of Wm J from the old buffers into the other
-  // buffers (4 + 2 reads, no read-modify-write), so a round costs two barriers.
+  // Per round: NP leader lanes turn (Gm_pp, Gm_qq, Gm_pq) into rotation coefficients, then the threads rebuild
+  // J^T Gm J and Wm J from the old buffers into the other buffers (no read-modify-write), by 2 x 2 blocks (below);
+  // a round costs two barriers.
   double *G2 = part;                 // the Gram partials are dead by now: reuse as the second buffers
   double *W2 = part + NLOC * NLOC;
-  double *cc = part + 2 * NLOC * NLOC;   // per index: cos, signed sin, partner
-  double *dd = cc + NLOC;
-  int *pr = (int *)(dd + NLOC);
+  double *cc = part + 2 * NLOC * NLOC;   // per index: cos, signed sin; per pair of the round (= per leader): p | q << 16
+  double *dd = cc + NLOC;                // (the pairs' (cos, sin) packed as one 16-byte entry per pair, read with
+  int *pr = (int *)(dd + NLOC);          //  ds_read_b128: 16.5 us per visit against 11.5 -- measured, not understood)
   double *Gc = Gm, *Gn = G2, *Wc = Wm, *Wn = W2;
   const double tol2 = tol * tol;
   int rotations = 0;
-  double max_sn = 0.0;                 // largest squared cosine between two columns rotated in this visit (leader lanes)
+  double mx_num = 0.0, mx_den = 1.0;   // largest squared cosine between two columns rotated in this visit, as a fraction:
+                                       // compared by cross-multiplication, divided once at the end (an fp64 division is ~25
+                                       // dependent instructions on the round's critical chain; the value only feeds a log line)
   for (int ls = 0; ls < local_sweeps; ++ls) {
     if (tid == 0) any_rot = 0;
     __syncthreads();
@@ -472,20 +474,40 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
           sn = (dl >= 0.0 ? ga : -ga) * (r1 * r2);
           ++rot_here;
           round_rot[rr % 3] = 1;
-          max_sn = __builtin_fmax(max_sn, (ga * ga) / (al * be));
+          if ((ga * ga) * mx_den > mx_num * (al * be)) { mx_num = ga * ga; mx_den = al * be; }
         }
-        cc[p] = cs; dd[p] = -sn; pr[p] = q;   // new_p = c old_p - s old_q
-        cc[q] = cs; dd[q] = sn;  pr[q] = p;   // new_q = s old_p + c old_q
+        cc[p] = cs; dd[p] = -sn;              // new_p = c old_p - s old_q
+        cc[q] = cs; dd[q] = sn;               // new_q = s old_p + c old_q
+        pr[tid] = p | (q << 16);              // the round's pairs, by leader
       }
       if (tid == 0) round_rot[(rr + 2) % 3] = 0;   // last read two barriers ago, next set two barriers on
       __syncthreads();
       if (!round_rot[rr % 3]) continue;            // nobody rotates: both buffers stay as they are
-      for (int e = tid; e < NLOC * NLOC; e += 1024) {
-        const int i = e / NLOC, j = e % NLOC;
-        const int pi = pr[i], pj = pr[j];
-        const double ci = cc[i], di = dd[i], cj = cc[j], dj = dd[j];
-        Gn[e] = ci * (cj * Gc[i * NLOC + j] + dj * Gc[i * NLOC + pj]) + di * (cj * Gc[pi * NLOC + j] + dj * Gc[pi * NLOC + pj]);
-        Wn[e] = cj * Wc[i * NLOC + j] + dj * Wc[i * NLOC + pj];
+      // A rotation round acts on 2 x 2 blocks: the block (pair a, pair b) of the matrix and the entries (row i, pair b) of
+      // Wm are rebuilt by ONE thread each -- one LDS read per output instead of four (two for Wm): with sixteen waves
+      // queueing at the LDS pipe the rebuild is a matter of its LDS instructions, 224 per round element by element, 112
+      // this way.  Every output is the same expression, in the same operation order, as the element-wise form.
+      for (int item = tid; item < NP * NP + NLOC * NP; item += 1024) {
+        if (item < NP * NP) {
+          const int a = item / NP, bq = item % NP;
+          const int pqa = pr[a], pqb = pr[bq];
+          const int pa = pqa & 0xffff, qa = pqa >> 16, pb = pqb & 0xffff, qb = pqb >> 16;
+          const double ca = cc[pa], sa = dd[qa], cb = cc[pb], sb = dd[qb];
+          const double g00 = Gc[pa * NLOC + pb], g01 = Gc[pa * NLOC + qb], g10 = Gc[qa * NLOC + pb], g11 = Gc[qa * NLOC + qb];
+          Gn[pa * NLOC + pb] = ca * (cb * g00 + (-sb) * g01) + (-sa) * (cb * g10 + (-sb) * g11);
+          Gn[pa * NLOC + qb] = ca * (cb * g01 + sb * g00) + (-sa) * (cb * g11 + sb * g10);
+          Gn[qa * NLOC + pb] = ca * (cb * g10 + (-sb) * g11) + sa * (cb * g00 + (-sb) * g01);
+          Gn[qa * NLOC + qb] = ca * (cb * g11 + sb * g10) + sa * (cb * g01 + sb * g00);
+        } else {
+          const int v = item - NP * NP;
+          const int i = v / NP, bq = v % NP;
+          const int pqb = pr[bq];
+          const int pb = pqb & 0xffff, qb = pqb >> 16;
+          const double cb = cc[pb], sb = dd[qb];
+          const double w0 = Wc[i * NLOC + pb], w1 = Wc[i * NLOC + qb];
+          Wn[i * NLOC + pb] = cb * w0 + (-sb) * w1;
+          Wn[i * NLOC + qb] = cb * w1 + sb * w0;
+        }
       }
       __syncthreads();
       double *t1 = Gc; Gc = Gn; Gn = t1;
@@ -507,7 +529,7 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
   __syncthreads();
   if (rotations) {
     atomicAdd(&flags[0], rotations);
-    atomicMax(&flags[3], __float_as_int((float)__builtin_sqrt(max_sn) * 1.0000002f));   // >= 0: the bit patterns order like the values
+    atomicMax(&flags[3], __float_as_int((float)__builtin_sqrt(mx_num / mx_den) * 1.0000002f));   // >= 0: the bit patterns order like the values
   }
   // ---- apply the accumulated rotation to the B panel, then to the V panel (same LDS buffer)
   apply_w();
@@ -791,18 +813,35 @@ __global__ __launch_bounds__(1024) void small_sym_eig_kernel(const double *__res
           ++rot_here;
           round_rot[rr % 3] = 1;
         }
-        cc[p] = cs; dd[p] = -sn; pr[p] = q;
-        cc[q] = cs; dd[q] = sn;  pr[q] = p;
+        cc[p] = cs; dd[p] = -sn;
+        cc[q] = cs; dd[q] = sn;
+        pr[tid] = p | (q << 16);              // the round's pairs, by leader
       }
       if (tid == 0) round_rot[(rr + 2) % 3] = 0;
       __syncthreads();
       if (!round_rot[rr % 3]) continue;
-      for (int e = tid; e < N * N; e += 1024) {
-        const int i = e / N, j = e % N;
-        const int pi = pr[i], pj = pr[j];
-        const double ci = cc[i], di = dd[i], cj = cc[j], dj = dd[j];
-        Gn[e] = ci * (cj * Gc[i * N + j] + dj * Gc[i * N + pj]) + di * (cj * Gc[pi * N + j] + dj * Gc[pi * N + pj]);
-        Wn[e] = cj * Wc[i * N + j] + dj * Wc[i * N + pj];
+      // rebuild by 2 x 2 blocks (see jac_block_kernel): the same expressions, half the LDS instructions
+      for (int item = tid; item < NP * NP + N * NP; item += 1024) {
+        if (item < NP * NP) {
+          const int a = item / NP, bq = item % NP;
+          const int pqa = pr[a], pqb = pr[bq];
+          const int pa = pqa & 0xffff, qa = pqa >> 16, pb = pqb & 0xffff, qb = pqb >> 16;
+          const double ca = cc[pa], sa = dd[qa], cb = cc[pb], sb = dd[qb];
+          const double g00 = Gc[pa * N + pb], g01 = Gc[pa * N + qb], g10 = Gc[qa * N + pb], g11 = Gc[qa * N + qb];
+          Gn[pa * N + pb] = ca * (cb * g00 + (-sb) * g01) + (-sa) * (cb * g10 + (-sb) * g11);
+          Gn[pa * N + qb] = ca * (cb * g01 + sb * g00) + (-sa) * (cb * g11 + sb * g10);
+          Gn[qa * N + pb] = ca * (cb * g10 + (-sb) * g11) + sa * (cb * g00 + (-sb) * g01);
+          Gn[qa * N + qb] = ca * (cb * g11 + sb * g10) + sa * (cb * g01 + sb * g00);
+        } else {
+          const int v = item - NP * NP;
+          const int i = v / NP, bq = v % NP;
+          const int pqb = pr[bq];
+          const int pb = pqb & 0xffff, qb = pqb >> 16;
+          const double cb = cc[pb], sb = dd[qb];
+          const double w0 = Wc[i * N + pb], w1 = Wc[i * N + qb];
+          Wn[i * N + pb] = cb * w0 + (-sb) * w1;
+          Wn[i * N + qb] = cb * w1 + sb * w0;
+        }
       }
       __syncthreads();
       double *t1 = Gc; Gc = Gn; Gn = t1;
