@@ -354,7 +354,7 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
   auto gcol = [&](int c) { return (c < WB) ? cI + c : cJ + (c - WB); };
 
   // the way in: two rows per lane (16 bytes), half the vector-memory and LDS-write instructions (b, ldb and bp are even, the
-  // matrices 16-byte aligned): 3.3 -> 2.9 us
+  // matrices 16-byte aligned): 3.3 -> 2.9 us.  (The way out is apply_w's own.)
   auto load_panel = [&](const double *M) {
     for (int c = wave; c < NLOC; c += 16) {
       const int gc = gcol(c);
@@ -362,15 +362,11 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
         *(d2v *)(P + (size_t)c * bp + i) = (gc < b) ? *(const d2v *)(M + (size_t)gc * ldb + i) : d2v{0.0, 0.0};
     }
   };
-  auto store_panel = [&](double *M) {     // (the way out stays one row per lane: with 16-byte LDS reads it took 0.9 us longer)
-    for (int c = wave; c < NLOC; c += 16) {
-      const int gc = gcol(c);
-      if (gc < b)
-        for (int i = lane; i < b; i += 64) M[(size_t)gc * ldb + i] = P[(size_t)c * bp + i];
-    }
-  };
-  // P <- P Wm : each wave owns row blocks of 16 rows (reads all its inputs before it writes)
-  auto apply_w = [&]() {
+  // M(:, the pair's columns) <- P Wm : each wave owns row blocks of 16 rows and stores its results straight to global memory
+  // -- D(row = local column fk + 4 reg, col = panel row fr): the 16 lanes of one fk write 128 contiguous bytes of a column
+  // of M.  (Through LDS and store_panel, as until round 3, the way out cost two more barriers and 16 LDS instructions per
+  // thread and panel.)
+  auto apply_w = [&](double *M) {
     for (int rb = wave; rb < b / 16; rb += 16) {
       const int i0 = rb * 16;
       double bf[NLOC / 4];
@@ -389,8 +385,10 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
 #pragma unroll
       for (int tc = 0; tc < NT16; ++tc)
 #pragma unroll
-        for (int reg = 0; reg < 4; ++reg)
-          P[(size_t)(tc * 16 + (lane >> 4) + 4 * reg) * bp + i0 + (lane & 15)] = acc[tc][reg];
+        for (int reg = 0; reg < 4; ++reg) {
+          const int gc = gcol(tc * 16 + (lane >> 4) + 4 * reg);
+          if (gc < b) M[(size_t)gc * ldb + i0 + (lane & 15)] = acc[tc][reg];
+        }
     }
   };
 
@@ -535,10 +533,8 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
     atomicMax(&flags[3], __float_as_int((float)__builtin_sqrt(mx_num / mx_den) * 1.0000002f));   // >= 0: the bit patterns order like the values
   }
   // ---- apply the accumulated rotation to the B panel, then to the V panel (same LDS buffer)
-  apply_w();
-  __syncthreads();
-  store_panel(B);
-  __syncthreads();
+  apply_w(B);
+  __syncthreads();          // every wave has read its rows of the B panel: the buffer may take the V panel
   jac_stamp(tr, 4);
   if (v_early) {
 #pragma unroll
@@ -552,10 +548,7 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
     load_panel(V);
   }
   __syncthreads();
-  apply_w();
-  __syncthreads();
-  store_panel(V);
-  __syncthreads();
+  apply_w(V);
   jac_stamp(tr, 5);
 }
 
