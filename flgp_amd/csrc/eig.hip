@@ -741,12 +741,18 @@ __global__ __launch_bounds__(64) void small_gemm_kernel(SmallGemmPair args, int 
   int t = 0;
   // the launch has one wave per SIMD at most (b / 16 squared waves), so registers are free: 32 steps of operands in
   // flight at a time -- with 8 the kernel was eight round trips to L2 long (7.5 us for 2 us of MFMAs)
+  // B's operands two k at a time (16 bytes per lane): a lane walks its own column of B, so every load instruction touches 64
+  // different cache lines whatever its width -- half as many of them (measured: 7.07 us per launch against 7.0, i.e. this
+  // is not what the launch waits for either)
   for (; t + 32 <= kn; t += 32) {
-    double av[32], bv[32];
+    double av[32];
+    d2v bv2[16];
 #pragma unroll
-    for (int u = 0; u < 32; ++u) { av[u] = pa[(size_t)(t + u) * b]; bv[u] = pb[t + u]; }
+    for (int u = 0; u < 32; ++u) av[u] = pa[(size_t)(t + u) * b];
 #pragma unroll
-    for (int u = 0; u < 32; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u], acc, 0, 0, 0);
+    for (int u = 0; u < 16; ++u) bv2[u] = *(const d2v *)(pb + t + 2 * u);
+#pragma unroll
+    for (int u = 0; u < 32; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv2[u >> 1][u & 1], acc, 0, 0, 0);
   }
   for (; t + 8 <= kn; t += 8) {
     double av[8], bv[8];
