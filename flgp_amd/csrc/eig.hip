@@ -366,12 +366,15 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
   // -- D(row = local column fk + 4 reg, col = panel row fr): the 16 lanes of one fk write 128 contiguous bytes of a column
   // of M.  (Through LDS and store_panel, as until round 3, the way out cost two more barriers and 16 LDS instructions per
   // thread and panel.)
-  auto apply_w = [&](double *M) {
-    for (int rb = wave; rb < b / 16; rb += 16) {
+  constexpr int VRB = 2;             // row blocks per wave whose V operands are held in registers (b <= 512)
+  auto apply_w = [&](double *M, const double (*pre)[NLOC / 4]) {
+    int q = 0;
+    for (int rb = wave; rb < b / 16; rb += 16, ++q) {
       const int i0 = rb * 16;
       double bf[NLOC / 4];
 #pragma unroll
-      for (int kk = 0; kk < NLOC / 4; ++kk) bf[kk] = P[(size_t)(kk * 4 + (lane >> 4)) * bp + i0 + (lane & 15)];
+      for (int kk = 0; kk < NLOC / 4; ++kk)
+        bf[kk] = pre ? pre[q < VRB ? q : 0][kk] : P[(size_t)(kk * 4 + (lane >> 4)) * bp + i0 + (lane & 15)];
       jd4 acc[NT16];
 #pragma unroll
       for (int tc = 0; tc < NT16; ++tc) {
@@ -395,18 +398,19 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
   load_panel(B);
   // The V panel is wanted only after the small eigenproblem is solved; its loads are issued now (registers) so that
   // their L2 / fabric latency -- the panels were last written by other XCDs -- passes behind the Gram product and
-  // the Jacobi rounds instead of in front of the second apply.  b <= 64 VPF rows per lane, else loaded late as before.
-  constexpr int VPF = 8;
-  const bool v_early = b <= 64 * VPF;
-  double vreg[NLOC / 16][VPF];
+  // the Jacobi rounds instead of in front of the second apply.  b <= 512 (two row blocks per wave), else loaded late as before.
+  // They are fetched in the layout the second apply multiplies them in (the wave's own 16-row blocks as MFMA operands: lane
+  // (fr, fk) holds row i0 + fr of local columns 4 kk + fk), so the V panel never sees LDS: no store, no barrier, no reads.
+  const bool v_early = b <= 16 * 16 * VRB;
+  double vfr[VRB][NLOC / 4];
   if (v_early) {
 #pragma unroll
-    for (int cc_ = 0; cc_ < NLOC / 16; ++cc_) {
-      const int gc = gcol(wave + 16 * cc_);
+    for (int q = 0; q < VRB; ++q) {
+      const int i0 = (wave + 16 * q) * 16;
 #pragma unroll
-      for (int m = 0; m < VPF; ++m) {
-        const int i = lane + 64 * m;
-        vreg[cc_][m] = (gc < b && i < b) ? V[(size_t)gc * ldb + i] : 0.0;
+      for (int kk = 0; kk < NLOC / 4; ++kk) {
+        const int gc = gcol(kk * 4 + (lane >> 4));
+        vfr[q][kk] = (gc < b && i0 < b) ? V[(size_t)gc * ldb + i0 + (lane & 15)] : 0.0;
       }
     }
   }
@@ -533,22 +537,16 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
     atomicMax(&flags[3], __float_as_int((float)__builtin_sqrt(mx_num / mx_den) * 1.0000002f));   // >= 0: the bit patterns order like the values
   }
   // ---- apply the accumulated rotation to the B panel, then to the V panel (same LDS buffer)
-  apply_w(B);
-  __syncthreads();          // every wave has read its rows of the B panel: the buffer may take the V panel
+  apply_w(B, nullptr);
   jac_stamp(tr, 4);
   if (v_early) {
-#pragma unroll
-    for (int cc_ = 0; cc_ < NLOC / 16; ++cc_)
-#pragma unroll
-      for (int m = 0; m < VPF; ++m) {
-        const int i = lane + 64 * m;
-        if (i < b) P[(size_t)(wave + 16 * cc_) * bp + i] = vreg[cc_][m];
-      }
+    apply_w(V, vfr);
   } else {
+    __syncthreads();        // every wave has read its rows of the B panel: the buffer may take the V panel
     load_panel(V);
+    __syncthreads();
+    apply_w(V, nullptr);
   }
-  __syncthreads();
-  apply_w(V);
   jac_stamp(tr, 5);
 }
 
