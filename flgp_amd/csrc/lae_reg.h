@@ -182,13 +182,22 @@ __global__ __launch_bounds__(64) void lae_reg_kernel(const double *__restrict__ 
 #pragma unroll
     for (int a = 0; a < R; ++a) v[a] = zc[a] + alpha * (zc[a] - zp[a]);
     const double g_v = half_sq_resid(v);
+    // grad = G v - x U^T with every entry an ascending chain over b (src/lae.cpp:104), from ONE pass over the upper triangle of
+    // the symmetric block: entry (a, b) is read once and feeds grad[b] (source a) and, for b > a, grad[a] (source b).  Row by
+    // row this hands every target its sources in ascending order -- a < t at rows a, then t itself, then b > t along row t --
+    // so the chains are the oracle's, with 55 LDS reads instead of 100 at r = 10 (the LDS pipe is what four such waves per
+    // CU share).
 #pragma unroll
     for (int a = 0; a < R; ++a) {
-      double acc = v[0] * Gab(0, a);
 #pragma unroll
-      for (int b = 1; b < R; ++b) acc = __builtin_fma(v[b], Gab(b, a), acc);
-      grad[a] = acc - xUt[a];
+      for (int b = a; b < R; ++b) {
+        const double g = Gab(a, b);
+        grad[b] = (a == 0) ? v[0] * g : __builtin_fma(v[a], g, grad[b]);          // source a into target b (a <= b)
+        if (b > a) grad[a] = __builtin_fma(v[b], g, grad[a]);                     // source b into target a (after its own row's diagonal)
+      }
     }
+#pragma unroll
+    for (int a = 0; a < R; ++a) grad[a] = grad[a] - xUt[a];
     for (int j = 0;; ++j) {
       const double beta = pow2(be + j);
       const double ib = inv_pow2(be + j);
