@@ -726,7 +726,8 @@ struct SmallGemmPair {
   SmallGemm g[2];
 };
 
-__global__ __launch_bounds__(64) void small_gemm_kernel(SmallGemmPair args, int b) {
+// (one wave per SIMD: the whole register file is this wave's)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void small_gemm_kernel(SmallGemmPair args, int b) {
   const SmallGemm g = args.g[blockIdx.z];
   const int lane = threadIdx.x, r = lane & 15, kq = lane >> 4;
   const int i0 = blockIdx.x * 16, j0 = blockIdx.y * 16;
@@ -742,6 +743,19 @@ __global__ __launch_bounds__(64) void small_gemm_kernel(SmallGemmPair args, int 
   // B's operands two k at a time (16 bytes per lane): a lane walks its own column of B, so every load instruction touches 64
   // different cache lines whatever its width -- half as many of them (measured: 7.07 us per launch against 7.0, i.e. this
   // is not what the launch waits for either)
+  // (b = 256: all 64 steps of operands in flight at once -- one round trip to L2 instead of two; the wave is alone on its SIMD
+  //  and may use the whole register file)
+  for (; t + 64 <= kn; t += 64) {
+    double av[64];
+    d2v bv2[32];
+#pragma unroll
+    for (int u = 0; u < 64; ++u) av[u] = pa[(size_t)(t + u) * b];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) bv2[u] = *(const d2v *)(pb + t + 2 * u);
+    __builtin_amdgcn_sched_barrier(0);   // (left to itself the scheduler sinks the loads between the MFMAs: a dozen in flight, 52 VGPRs)
+#pragma unroll
+    for (int u = 0; u < 64; ++u) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv2[u >> 1][u & 1], acc, 0, 0, 0);
+  }
   for (; t + 32 <= kn; t += 32) {
     double av[32];
     d2v bv2[16];
