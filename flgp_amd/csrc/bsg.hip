@@ -405,8 +405,14 @@ __global__ __launch_bounds__(256) void bsg_pre_kernel(const int *__restrict__ rp
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int jj = (j + u < ne) ? j + u : j;
-          const int k = __shfl(kc, jj, 64);
-          vv[u] = (j + u < ne) ? __shfl(vc, jj, 64) : 0.0;
+          // the entry is the same for every lane: read it from lane jj into scalar registers (a shuffle is a trip through the
+          // LDS crossbar per 32 bits, three per entry, in front of every gather's address)
+          const int k = __builtin_amdgcn_readlane(kc, jj);
+          const unsigned long long vbits = __builtin_bit_cast(unsigned long long, vc);
+          const unsigned vlo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)vbits, jj);
+          const unsigned vhi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(vbits >> 32), jj);
+          const double vsel = __builtin_bit_cast(double, ((unsigned long long)vhi << 32) | vlo);
+          vv[u] = (j + u < ne) ? vsel : 0.0;
           const bd2 *x = (const bd2 *)(Xt + (size_t)k * b + (okc ? c : 0));
           xa[u] = x[0];
           xb[u] = x[1];
