@@ -1517,8 +1517,11 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
       // the error contracts quadratically, e <- (3/4) e^2 + O(e^3): run the predicted number of
       // iterations without talking to the host, then check once (|I - S|_F over-estimates e, so
       // the prediction errs on the safe side); a block that does not contract falls through to Jacobi
+      // (|I - S|_F over-estimates the spectral norm that contracts: the prediction starts from 0.3 |I - S|_F -- over eight start
+      //  blocks at configs[2] one to five steps fewer per orthonormalisation with the closing check still at rounding level,
+      //  13.84 -> 13.70 ms; a prediction that falls short fails that check and the block takes the scaled iteration below)
       int kmax = 2;
-      for (double e = std::min(delta * 0.01 * tuning("eig_ns_e0_pct", 100), 0.95); e > 1e-17 && kmax < 40; ++kmax) e = (e < 0.5) ? 0.8 * e * e : 0.5 * e + 0.4 * e * e;
+      for (double e = std::min(delta * 0.01 * tuning("eig_ns_e0_pct", 30), 0.95); e > 1e-17 && kmax < 40; ++kmax) e = (e < 0.5) ? 0.8 * e * e : 0.5 * e + 0.4 * e * e;
       bool ok = false;
       for (int k = 0; k < kmax; ++k) {
         FLGP_TRY(small_gemm(Zc, Yc, -0.5, 1.5, w.Id, Mm));
