@@ -1593,7 +1593,7 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
         // The step count follows from l alone, so the host is not asked until the end.
         int kdyn = 0;
         {
-          double ell = std::pow(10.0, -(double)tuning("eig_ns_ell0_exp", 5));
+          double ell = std::pow(10.0, -(double)tuning("eig_ns_ell0_exp", 4));
           const int tail = tuning("eig_ns_tail", 2);
           int after = 0;
           while (kdyn < 60 && tuning("eig_ns_dynamic", 1)) {
