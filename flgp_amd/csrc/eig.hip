@@ -996,13 +996,15 @@ __global__ void row_scale_kernel(const double *__restrict__ Z, int b, const doub
 // res[j] = | Z(:,j) - theta_j Q(:,j) |_2 , j < K ; also column norms of Q when Z == nullptr
 // (host: optional host-visible copy of what the step's one round trip asks for -- [0, gridDim.x) the residuals, [b, 2b) theta)
 __global__ void resid_kernel(const double *__restrict__ Z, const double *__restrict__ Q, int s, int ld,
-                             const double *__restrict__ theta, double *__restrict__ res, double *__restrict__ host, int b) {
+                             const double *__restrict__ theta, double *__restrict__ res, double *__restrict__ host, int b,
+                             int tstride) {   // tstride = b + 1: theta_j = the diagonal of a b x b matrix (and no copy of theta to the host)
   const int j = blockIdx.x;
   __shared__ double red[256];
   double acc = 0.0;
+  const double th = Z ? theta[(size_t)j * tstride] : 0.0;
   for (int i = threadIdx.x; i < s; i += blockDim.x) {
     const double q = Q[(size_t)j * ld + i];
-    const double d = Z ? Z[(size_t)j * ld + i] - theta[j] * q : q;
+    const double d = Z ? Z[(size_t)j * ld + i] - th * q : q;
     acc = __builtin_fma(d, d, acc);
   }
   red[threadIdx.x] = acc;
@@ -1014,7 +1016,8 @@ __global__ void resid_kernel(const double *__restrict__ Z, const double *__restr
   if (threadIdx.x == 0) res[j] = __builtin_sqrt(red[0]);
   if (host) {
     if (threadIdx.x == 0) host[j] = __builtin_sqrt(red[0]);
-    for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < b; q += gridDim.x * blockDim.x) host[b + q] = theta[q];
+    if (tstride == 1)
+      for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < b; q += gridDim.x * blockDim.x) host[b + q] = theta[q];
     __threadfence_system();
   }
 }
@@ -1702,13 +1705,15 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
   FLGP_HIP(stream_wait(st));   // the set-up's bookkeeping (and the a-priori bounds) have arrived on the host
   bsg_finish(bs);
 
-  std::vector<double> theta(b), res(K);
+  std::vector<double> theta(b), res(K), pred(K, 1.0);   // pred: see plan_filter (soft locking)
+  bool soft_on = tuning("eig_soft_lock", 0) != 0;   // (off by default: see NOTEBOOK r04-1 -- 8 iterations instead of 10.4, but every one waits for two Jacobi sweeps)
+  int last_m = 0;                                  // degree of the filter applied last
   int gprods = 0, it = 0;
   const int max_it = 80;
   bool converged = false;
   double *result = nullptr;
   double rmax_prev = 1.0;
-  const int rr_every = tuning("eig_rr_every", 3);
+  const int rr_every = soft_on ? 1 : tuning("eig_rr_every", 3);   // (soft locking needs every step's residuals; skipped steps were a saving of the 10-iteration schedule)
   int since_rr = 0, it_meas = 0;
   double rate = 0.1, rmax_meas = 0.0;
 
@@ -1733,12 +1738,30 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
     // K-th eigenvalue rises from 1.38 to 1.46, 17 % fewer products
     const double lo = (lambda_lo > 0.0 && lambda_lo < 0.5 * cut) ? lambda_lo : 0.0;
     fp.e = 0.5 * (cut - lo); fp.c = 0.5 * (cut + lo);
-    const double g1 = (top - fp.c) / fp.e;      // >= 1
+    // Soft locking (round 4).  The amplification cap exists for the columns that are still moving: a filtered column j
+    // carries the rounding noise of the recurrence along the higher directions amplified by p(th_i) / p(th_j).  Along a
+    // CONVERGED Ritz direction that noise is removed by the Gram-Schmidt pass below to the accuracy of the converged vector,
+    // however large it was; so the cap is taken at the first Ritz value whose pair has NOT met the tolerance, not at the
+    // top of the spectrum.  At BASELINE configs[2] the sixteen cluster eigenvalues (0.994..1, then a gap to 0.66) converge
+    // by iteration 3 and the prefix grows by ~50 pairs per iteration: degrees 8 8 13 22 12 instead of 8 each, 7 outer
+    // iterations instead of 10 with the same number of products (scripts/model_chfsi2.py soft=1; a cap of 1e9 still
+    // converges in the model, 1e10 does not, and degrees beyond ~24 stop paying -- mmax).  The polynomial is still scaled to 1
+    // at the true top (sigma1), so converged columns grow by up to T_m(g_top) ~ 1e23 per iteration and are renormalised by
+    // the orthonormalisation's column scaling.  `pred` = the residuals of the last Rayleigh-Ritz step, contracted by the
+    // filters applied since (overlapped iterations plan their filter before the step's own residuals are known).
+    int n_soft = 0;
+    if (it_ >= 2 && soft_on) {
+      const double lim = tol * std::max(theta[0], 1e-300);
+      while (n_soft < K - 1 && pred[n_soft] <= lim) ++n_soft;
+    }
+    const double top_act = std::max(theta[n_soft], 1e-300);
+    const double g1 = (std::min(top, top_act) - fp.c) / fp.e;      // >= 1
     // degree: amplification T_m(g1) of the top direction capped per outer iteration
     // (gentler while the block is still far from the invariant subspace)
     const double amp = std::pow(10.0, (double)((it_ < 2) ? tuning("eig_amp_exp_early", 3) : tuning("eig_amp_exp", 8)));
     int m = (int)std::floor(std::acosh(amp) / std::acosh(std::max(g1, 1.0 + 1e-12)));
-    fp.m = std::max(2, std::min(m, 40));
+    const int m_cap = n_soft ? tuning("eig_soft_mmax", 24) : 40;
+    fp.m = std::max(2, std::min(m, m_cap));
     // Landing.  A filter of degree m contracts the residual of the K-th pair -- the slowest -- by 1 / T_m(g_K) ~ 2 exp(-m a),
     // a = acosh(g_K), g_K the K-th Ritz value on the filter's own scale (measured at configs[2]: 0.0526 per iteration
     // against 1 / T_8(1.1055) = 0.0526).  With the last measured residual that gives the iterations still needed at the
@@ -1760,13 +1783,24 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
           // (one iteration fewer at most, and three degrees more at most: with five or eight more per iteration the block
           //  loses accuracy faster than the filter gains -- 14 and 15 iterations instead of 10)
           if (n0 >= 2 && degree_for(n0 - 1) <= fp.m + tuning("eig_landing_boost", 3)) mm = degree_for(n0 - 1);
-          fp.m = std::max(2, std::min(mm, 40));
+          fp.m = std::max(2, std::min(mm, m_cap));
           rate = std::min(0.5, std::max(1e-4, 2.0 * std::exp(-fp.m * a)));
         }
       }
     }
     fp.sigma1 = fp.e / (top - fp.c);
+    if (tuning("eig_verbose", 0)) fprintf(stderr, "[flgp eig]   filter it=%d: soft prefix %d, active top %.4f, cut %.4f, lo %.3f, degree %d\n", it_, n_soft, top_act, cut, lo, fp.m);
     return fp;
+  };
+  // what a filter just applied does to the residual of pair j: 1 / T_m(g_j) ~ 2 exp(-m acosh g_j), times a safety factor
+  // (the model: measured contraction within 3x of this for every pair once the block is past its first two iterations)
+  auto contract_pred = [&](const FilterPlan &fp) {
+    last_m = fp.m;
+    const double safety = (double)tuning("eig_soft_safety", 10);
+    for (int j = 0; j < K; ++j) {
+      const double g = (theta[j] - fp.c) / fp.e;
+      if (g > 1.0) pred[j] *= std::min(1.0, safety * 2.0 * std::exp(-fp.m * std::acosh(g)));
+    }
   };
   // p(G) A given B = G A; A, f1, f2 are overwritten (B is not); returns the buffer with the result and
   // one buffer that is free afterwards
@@ -1817,15 +1851,28 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
   // the ONE host round trip of a Rayleigh-Ritz step: brings the residuals and the sorted Ritz values over together
   std::vector<double> rt(2 * (size_t)b);
   auto residuals = [&](const double *A, const double *B, double *rmax_out) -> int {
-    hipLaunchKernelGGL(resid_kernel, dim3(K), dim3(256), 0, st, B, A, s, s, w.theta, w.res, rt_d, b);
+    hipLaunchKernelGGL(resid_kernel, dim3(K), dim3(256), 0, st, B, A, s, s, w.theta, w.res, rt_d, b, 1);
     FLGP_TRY(check_launch("resid_kernel"));
     const double *rtp = rt_h;
     if (!rt_d) { FLGP_HIP(hipMemcpyAsync(rt.data(), w.res, sizeof(double) * 2 * b, hipMemcpyDeviceToHost, st)); rtp = rt.data(); }
     FLGP_HIP(stream_wait(st));
     double rmax = 0.0;
-    for (int j = 0; j < K; ++j) { res[j] = rtp[j]; rmax = std::max(rmax, res[j]); }
+    for (int j = 0; j < K; ++j) { res[j] = rtp[j]; pred[j] = res[j]; rmax = std::max(rmax, res[j]); }
     for (int j = 0; j < b; ++j) theta[j] = rtp[b + j];
     *rmax_out = rmax;
+    return FLGP_OK;
+  };
+  // Overlapped iterations plan their filter before the Rayleigh-Ritz step has finished.  The columns of Q are last
+  // iteration's Ritz vectors, filtered, cleaned and orthonormalised -- nearly Ritz -- so | Z_j - Q_j T_jj | is a residual of
+  // an approximate pair in its own right, and an upper estimate of the Ritz pair's: a MEASURED prefix of converged pairs for
+  // the soft locking, one small kernel and one host round trip (~25 us) behind the Gram product that is waited for anyway.
+  auto residual_estimate = [&](const double *Qc, const double *Zc, const double *Tm) -> int {
+    hipLaunchKernelGGL(resid_kernel, dim3(K), dim3(256), 0, st, Zc, Qc, s, s, Tm, w.res, rt_d, b, b + 1);
+    FLGP_TRY(check_launch("resid_kernel"));
+    const double *rtp = rt_h;
+    if (!rt_d) { FLGP_HIP(hipMemcpyAsync(rt.data(), w.res, sizeof(double) * K, hipMemcpyDeviceToHost, st)); rtp = rt.data(); }
+    FLGP_HIP(stream_wait(st));
+    for (int j = 0; j < K; ++j) pred[j] = rtp[j];
     return FLGP_OK;
   };
   auto after_rr = [&](double rmax, double top, bool overlapped) {   // book-keeping shared by both orders
@@ -1841,8 +1888,18 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
       for (int j = 0; j < K; ++j) nconv += res[j] <= tol * top;
       fprintf(stderr, "[flgp eig] it=%d gprods=%d theta0=%.15g thetaK=%.6g cut=%.6g rmax=%.3e cond=%.2e sweeps=%d conv=%d prefix=%d%s\n",
               it, gprods, theta[0], theta[K - 1], theta[b - 1], rmax, cond, sweeps, nconv, npre, overlapped ? " (overlapped)" : "");
+      if (tuning("eig_verbose", 0) > 2) {
+        int shown = 0;
+        for (int j = 0; j < K && shown < 8; ++j) if (res[j] > tol * top) { fprintf(stderr, "    pair %d theta %.9f res %.2e\n", j, theta[j], res[j]); ++shown; }
+      }
     }
     if (rmax <= tol * top) return true;
+    // the soft locking's safeguard: residuals that GROW say a filter was stronger than the block could take (a pair counted
+    // as converged was not) -- back to the cap at the top of the spectrum for the rest of the solve
+    if (soft_on && it >= 3 && rmax_meas > 0.0 && rmax / top > 4.0 * rmax_meas) {
+      soft_on = false;
+      if (tuning("eig_verbose", 0)) fprintf(stderr, "[flgp eig] residual grew (%.2e -> %.2e): soft locking off\n", rmax_meas, rmax / top);
+    }
     if (it >= 3 && rmax_meas > 0.0 && rmax / top < rmax_meas) {
       const double rt = std::pow((rmax / top) / rmax_meas, 1.0 / (double)(it - it_meas));
       rate = std::min(0.5, std::max(0.02, rt));
@@ -1886,18 +1943,21 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
       since_rr = 0;
       FLGP_TRY(gram_small(Q, Z, w.T));
       FLGP_HIP(hipEventRecord(side.ev, st));
-      FLGP_HIP(hipMemcpyAsync(w.Qold, Q, sizeof(double) * (size_t)tot, hipMemcpyDeviceToDevice, st));
-      const FilterPlan fp = plan_filter(top, it);
-      FLGP_TRY(apply_filter(fp, Q, Z, F[1], F[2], &cur, &spare));
-      // the other stream: T = W Th W^T
+      // the other stream first (round 4: it used to be enqueued BEHIND the filter's launches, and the host needs ~0.4 ms to
+      // enqueue a filter of degree 24 -- the refinement, which is the longer of the two, started that much late): T = W Th W^T
       FLGP_HIP(hipStreamWaitEvent(side.st, side.ev, 0));
       {
-        const int nsw = std::max(1, (rmax_prev > 1e-4 * tuning("eig_refine3_above_e4", 2000) ? 3 : (rmax_prev > 1e-8 * tuning("eig_refine2_above_e8", 100) ? 2 : 1)) - tuning("eig_refine_minus", 0));
+        int nsw = std::max(1, (rmax_prev > 1e-4 * tuning("eig_refine3_above_e4", 2000) ? 3 : (rmax_prev > 1e-8 * tuning("eig_refine2_above_e8", 100) ? 2 : 1)) - tuning("eig_refine_minus", 0));
+        if (last_m >= tuning("eig_sweeps2_from_m", 11)) nsw = std::max(nsw, 2);   // a strong filter leaves T further from diagonal than the residual says (measured: one sweep after degree 24 un-converged the cluster pairs)
         FLGP_TRY(jacobi_refine(side.st, w.T, b, K, w, lam, &sweeps, nsw, false));
         sweeps = nsw;
       }
       FLGP_TRY(sorted_basis_dev(side.st, b, w));       // order and W on the device: the host is not asked
       FLGP_HIP(hipEventRecord(side.ev, side.st));
+      FLGP_HIP(hipMemcpyAsync(w.Qold, Q, sizeof(double) * (size_t)tot, hipMemcpyDeviceToDevice, st));
+      if (soft_on && tuning("eig_soft_estimate", 1)) FLGP_TRY(residual_estimate(Q, Z, w.T));
+      const FilterPlan fp = plan_filter(top, it);
+      FLGP_TRY(apply_filter(fp, Q, Z, F[1], F[2], &cur, &spare));
       FLGP_HIP(hipStreamWaitEvent(st, side.ev, 0));
       // the two buffers of {Q, F1, F2} that do not hold the filtered block take A and B
       double *trio[3] = {Q, F[1], F[2]};
@@ -1909,6 +1969,7 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
       FLGP_TRY(residuals(A, B, &rmax));
       top = std::max(theta[0], 1e-300);
       if (after_rr(rmax, top, true)) { converged = true; result = A; break; }
+      contract_pred(fp);                  // (the residuals just measured are those of the block BEFORE this iteration's filter)
       FLGP_TRY(rotate(cur, w.W, Z));      // the filtered block in the new Ritz order (Z is free by now)
       FLGP_HIP(hipMemcpyAsync(w.Qold, A, sizeof(double) * (size_t)tot, hipMemcpyDeviceToDevice, st));
       free1 = cur; free2 = Z;
@@ -1933,6 +1994,7 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
           FLGP_TRY(jacobi_eig(st, w.T, b, b, w, lam, nullptr, sweeps, 1e6, false, false));
         } else {
           sweeps = std::max(1, (rmax_prev > 1e-4 * tuning("eig_refine3_above_e4", 2000) ? 3 : (rmax_prev > 1e-8 * tuning("eig_refine2_above_e8", 100) ? 2 : 1)) - tuning("eig_refine_minus", 0));
+          if (last_m >= tuning("eig_sweeps2_from_m", 11)) sweeps = std::max(sweeps, 2);
           FLGP_TRY(jacobi_refine(st, w.T, b, K, w, lam, nullptr, sweeps, false));
         }
         FLGP_TRY(sorted_basis_dev(st, b, w));
@@ -1965,6 +2027,7 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
       // the Ritz vectors are needed again after the filter (see below): keep a copy
       FLGP_HIP(hipMemcpyAsync(w.Qold, A, sizeof(double) * (size_t)tot, hipMemcpyDeviceToDevice, st));
       FLGP_TRY(apply_filter(fp, A, B, free1, free2, &cur, &spare));
+      if (it >= skip_rr_n) contract_pred(fp);
     }
     // ---- de-contaminate: a filtered column y_j = p(G) q_j carries its error components along the
     //      higher Ritz directions amplified by p(th_i)/p(th_j) (up to `amp`).  One Gram-Schmidt pass
