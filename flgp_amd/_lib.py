@@ -118,6 +118,10 @@ _SIGNATURES = {
                                                         P, P, c_int, P]),
     "flgp_heat_kernel_covariance_multi": (c_int, [P, c_int, c_int, c_int, P, c_int, c_int, c_int, c_double, c_int, c_char_p,
                                                   c_char_p, c_int, c_double, c_int, P, P]),
+    "flgp_heat_kernel_covariance_rank": (c_int, [P, P, c_long, c_int, c_long, c_long, c_int, c_int, P, c_int, c_int, c_int, c_double,
+                                                 c_int, c_char_p, c_char_p, c_int, c_double, P, c_long, P]),
+    "flgp_comm_abort": (None, [P]),
+    "flgp_comm_agree": (c_int, [P, c_int, P]),
     "flgp_dev_hk_workspace": (c_size_t, [c_int, c_int, c_int, c_int]),
 }
 

@@ -381,7 +381,15 @@ def _devices_from_env():
     """FLGP_DEVICES="0,1,2,3": the GPUs the row-sharded entry point uses (the R shim reads the same variable)."""
     import os
     v = os.environ.get("FLGP_DEVICES", "").strip()
-    return [int(x) for x in v.split(",") if x.strip() != ""] if v else None
+    if not v:
+        return None
+    try:
+        devs = [int(x) for x in v.split(",")]
+    except ValueError:
+        raise FlgpError(-1, "FLGP_DEVICES=%r is not a comma-separated list of device numbers" % v) from None
+    if any(x < 0 for x in devs):
+        raise FlgpError(-1, "FLGP_DEVICES=%r holds a negative device number" % v)
+    return devs
 
 
 def heat_kernel_covariance_cpp(X, X_new, s, r, t, K, models, nstart, epsilon, U=None, devices=None):
@@ -399,7 +407,7 @@ def heat_kernel_covariance_cpp(X, X_new, s, r, t, K, models, nstart, epsilon, U=
     H = np.zeros((n, m), order="F")
     if devices is None:
         devices = _devices_from_env()
-    if devices is not None and len(devices) > 1:
+    if devices is not None and len(devices) >= 1:      # (a single id selects that GPU: the C entry switches to it and back)
         dev = np.ascontiguousarray(devices, dtype=np.int32)
         check(_lib.lib().flgp_heat_kernel_covariance_multi(_ptr(X_all), n, m, d, _ptr(U), s, U.shape[1], int(r), float(t), int(K),
                                                            _b(models["kernel"]), _b(models["gl"]), int(bool(models["root"])),

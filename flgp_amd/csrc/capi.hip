@@ -334,9 +334,9 @@ static std::condition_variable g_ring_cv;
 static std::vector<PinnedRing *> g_rings;
 struct RingLease {
   PinnedRing *r = nullptr;
-  RingLease() {
+  explicit RingLease(int at_least = 0) {     // at_least: the ranks of one multi-GPU call each need a ring at the same time
     std::unique_lock<std::mutex> lk(g_ring_mu);
-    const size_t cap = (size_t)std::max(1, tuning("hk_rings_max", 2));
+    const size_t cap = (size_t)std::max(std::max(1, tuning("hk_rings_max", 2)), at_least);
     for (;;) {
       for (PinnedRing *c : g_rings) if (!c->busy) { r = c; break; }
       if (!r && g_rings.size() < cap) { r = new PinnedRing(); g_rings.push_back(r); }
@@ -432,6 +432,54 @@ static int hk_ranges_to_host(hipStream_t st, const double *d_values, int K, doub
   (void)hipStreamSynchronize(cp.s);
   (void)hipStreamSynchronize(st);
   if (rc == FLGP_ERR_HIP) set_error("HIP error in the pipelined copy of H");
+  return rc;
+}
+
+// A device matrix (rows x cols, column-major, ld = rows) to the caller's pageable memory with column c at H + c * ldh
+// (ldh >= rows: a rank's row block of the whole H), through the pinned ring: the DMA of block c runs while a few host
+// threads copy block c-1 out of its pinned buffer.  What the multi-GPU host entry uses per rank (round 4; a single
+// hipMemcpy2DAsync into pageable memory staged through the runtime's bounce buffer on one thread before).
+static int d2h_cols_pipelined(hipStream_t st, const double *dM, long rows, int cols, double *H, long ldh, int rings_at_least) {
+  if (rows <= 0 || cols <= 0) return FLGP_OK;
+  const size_t colbytes = sizeof(double) * (size_t)rows;
+  int nc = (int)std::max<size_t>(1, ((size_t)std::max(1, tuning("hk_block_mb", 512)) << 19) / colbytes);   // half of the GEMM path's block: nothing to overlap with but the copies themselves
+  if (nc > cols) nc = cols;
+  const int nblk = ceil_div(cols, nc);
+  RingLease lease(rings_at_least);
+  PinnedRing &ring = *lease.r;
+  FLGP_TRY(ring.ensure(colbytes * nc));
+  EventSet evs;
+  FLGP_TRY(evs.create());
+  hipEvent_t *dma_done = evs.e;
+  const int nthreads = std::max(1, std::min(tuning("hk_copy_threads", 8), (int)std::thread::hardware_concurrency()));
+  std::vector<std::thread> copiers[2];
+  auto join = [&](int q) { for (auto &th : copiers[q]) th.join(); copiers[q].clear(); };
+  int rc = FLGP_OK;
+  for (int c = 0; c <= nblk && rc == FLGP_OK; ++c) {
+    const int q = c & 1;
+    if (c < nblk) {
+      const int b0 = c * nc, w = std::min(nc, cols - b0);
+      join(q);                                   // the host copy of block c-2 has left pinned buffer q
+      if (hipMemcpyAsync(ring.buf[q], dM + (size_t)b0 * rows, colbytes * w, hipMemcpyDeviceToHost, st) != hipSuccess ||
+          hipEventRecord(dma_done[q], st) != hipSuccess) rc = FLGP_ERR_HIP;
+    }
+    if (c >= 1 && rc == FLGP_OK) {
+      const int p = (c - 1) & 1, b0 = (c - 1) * nc, w = std::min(nc, cols - b0);
+      if (hipEventSynchronize(dma_done[p]) != hipSuccess) { rc = FLGP_ERR_HIP; break; }
+      const char *src = (const char *)ring.buf[p];
+      const int per = (w + nthreads - 1) / nthreads;
+      for (int tq = 0; tq < nthreads; ++tq) {
+        const int c0 = tq * per, c1 = std::min(w, c0 + per);
+        if (c0 >= c1) break;
+        copiers[p].emplace_back([=] {
+          for (int cc = c0; cc < c1; ++cc) memcpy(H + (size_t)(b0 + cc) * (size_t)ldh, src + colbytes * (size_t)cc, colbytes);
+        });
+      }
+    }
+  }
+  join(0); join(1);
+  (void)hipStreamSynchronize(st);
+  if (rc == FLGP_ERR_HIP) set_error("HIP error in the pipelined copy of a rank's rows of H");
   return rc;
 }
 
@@ -1292,6 +1340,62 @@ extern "C" int flgp_dev_heat_kernel_covariance_sharded(void *stream, const flgp_
   return FLGP_OK;
 }
 
+// One rank of the sharded path at the HOST boundary: this rank's rows [row_lo, row_lo + n_loc) of X_all arrive as host
+// memory (column j at X_rows + j * ldx_host) and its rows of H leave the same way (column b at H_rows + b * ldh_host).
+// Upload -> input check -> the ranks AGREE that all of them can go on (flgp_comm_agree: a NaN in one shard or a failed
+// allocation makes every rank return, nobody waits in an exchange for a rank that has left) -> the sharded device path ->
+// H through the pinned, pipelined copy.  flgp_heat_kernel_covariance_multi runs one of these per device on its own host
+// thread; a one-process-per-GPU front end (bench.py under torchrun; R with Rmpi) calls it once per process.
+extern "C" int flgp_heat_kernel_covariance_rank(const flgp_comm *comm, const double *X_rows, long ldx_host, int n_loc,
+                                                long n_global, long row_lo, int m, int d, const double *U, int s, int ucols,
+                                                int r, double t, int K, const char *kernel, const char *gl, int root,
+                                                double epsilon, double *H_rows, long ldh_host, int *info) {
+  const int world = comm ? comm->world : 1;
+  Stream st;
+  DevBuf dX, dUall, dHl;
+  // ---- everything that can fail on ONE rank alone, up to the first exchange
+  auto prepare = [&]() -> int {
+    int se = 0;
+    FLGP_TRY(parse_kernel(kernel, &se));
+    const int glc = flgp_parse_gl(gl);
+    if (glc < 0) return glc;
+    FLGP_REQUIRE(X_rows && U && H_rows, "heat_kernel_covariance_rank: null pointer");
+    FLGP_REQUIRE(n_loc >= 1 && ldx_host >= n_loc && ldh_host >= n_loc && d >= 1 && s >= 1, "heat_kernel_covariance_rank: bad shape");
+    FLGP_REQUIRE(n_global >= n_loc && row_lo >= 0 && row_lo + n_loc <= n_global && m >= 1 && (long)m <= n_global,
+                 "heat_kernel_covariance_rank: rows [%ld, %ld) / m = %d do not fit n = %ld", row_lo, row_lo + n_loc, m, n_global);
+    FLGP_REQUIRE(ucols == d || ucols == d + 1, "U must have d or d+1 columns (d=%d, got %d)", d, ucols);
+    FLGP_REQUIRE(glc != FLGP_GL_CLUSTER_NORMALIZED || ucols == d + 1,
+                 "gl=\"cluster-normalized\" needs the cluster sizes in column d+1 of U (the reference reads out of bounds here)");
+    FLGP_TRY(st.create());
+    FLGP_TRY(dX.alloc(sizeof(double) * (size_t)n_loc * d));
+    FLGP_TRY(dUall.alloc(sizeof(double) * (size_t)s * ucols));
+    FLGP_TRY(dHl.alloc(sizeof(double) * (size_t)n_loc * m));
+    FLGP_HIP(hipMemcpy2DAsync(dX.p, sizeof(double) * (size_t)n_loc, X_rows, sizeof(double) * (size_t)ldx_host, sizeof(double) * (size_t)n_loc, d,
+                              hipMemcpyHostToDevice, st.s));
+    FLGP_TRY(h2d(dUall.p, U, sizeof(double) * (size_t)s * ucols, st.s));
+    InputCheck ck;
+    FLGP_TRY(ck.begin(st.s));
+    FLGP_TRY(ck.finite(st.s, dX.as<double>(), (long)n_loc * d));
+    FLGP_TRY(ck.finite(st.s, dUall.as<double>(), (long)s * ucols));
+    return ck.verdict(st.s, "points / anchors");
+  };
+  int rc = prepare();
+  if (world > 1) {
+    if (!st.s) {                                // not even a stream: this rank cannot take part in the agreement
+      flgp_comm_abort(comm);
+      return rc != FLGP_OK ? rc : FLGP_ERR_HIP;
+    }
+    rc = flgp_comm_agree(comm, rc, st.s);
+  }
+  if (rc != FLGP_OK) return rc;
+  const double *sizes = (ucols == d + 1) ? dUall.as<double>() + (size_t)d * s : nullptr;
+  FLGP_TRY(flgp_dev_heat_kernel_covariance_sharded(st.s, comm, dX.as<double>(), n_loc, n_loc, d, n_global, row_lo, dUall.as<double>(), s, s,
+                                                   sizes, m, r, t, K, kernel, gl, root, epsilon, dHl.as<double>(), n_loc, nullptr, nullptr,
+                                                   0, info));
+  dX.release();
+  return d2h_cols_pipelined(st.s, dHl.as<double>(), n_loc, m, H_rows, ldh_host, world);
+}
+
 extern "C" int flgp_heat_kernel_covariance_multi(const double *X_all, int n, int m, int d, const double *U, int s, int ucols,
                                                  int r, double t, int K, const char *kernel, const char *gl, int root,
                                                  double epsilon, int ndev, const int *devices, double *H) {
@@ -1305,6 +1409,16 @@ extern "C" int flgp_heat_kernel_covariance_multi(const double *X_all, int n, int
   FLGP_REQUIRE(ucols == d || ucols == d + 1, "U must have d or d+1 columns (d=%d, got %d)", d, ucols);
   FLGP_REQUIRE(glc != FLGP_GL_CLUSTER_NORMALIZED || ucols == d + 1,
                "gl=\"cluster-normalized\" needs the cluster sizes in column d+1 of U (the reference reads out of bounds here)");
+  int ndev_sys = 0;
+  FLGP_HIP(hipGetDeviceCount(&ndev_sys));
+  for (int a = 0; a < ndev; ++a)
+    FLGP_REQUIRE(devices[a] >= 0 && devices[a] < ndev_sys, "heat_kernel_covariance_multi: device %d is not one of the %d visible devices", devices[a], ndev_sys);
+  // the caller's current device is left as it was found, on every way out (the peer-enable loop used to move it)
+  struct DeviceGuard {
+    int dev = -1;
+    DeviceGuard() { if (hipGetDevice(&dev) != hipSuccess) dev = -1; }
+    ~DeviceGuard() { if (dev >= 0) (void)hipSetDevice(dev); }
+  } guard;
   if (ndev == 1) {
     FLGP_TRY(flgp_set_device(devices[0]));
     return flgp_heat_kernel_covariance(X_all, n, m, d, U, s, ucols, r, t, K, kernel, gl, root, epsilon, H);
@@ -1337,35 +1451,14 @@ extern "C" int flgp_heat_kernel_covariance_multi(const double *X_all, int n, int
   }
   std::vector<int> rcs((size_t)ndev, FLGP_OK);
   std::vector<std::string> msgs((size_t)ndev);
+  const int fail_rank = tuning("multi_test_fail_rank", -1);     // test hook: this rank leaves without a word, as after a failed hipSetDevice (exercises the abort route: its peers are waiting in the agreement)
   auto rank_main = [&](int q) -> int {
     FLGP_HIP(hipSetDevice(devices[q]));
-    Stream st;
-    FLGP_TRY(st.create());
     const long base = n / ndev, rem = n % ndev;
     const long lo = q * base + std::min<long>(q, rem), n_loc = base + (q < rem ? 1 : 0);
-    DevBuf dX, dUall, dHl;
-    FLGP_TRY(dX.alloc(sizeof(double) * (size_t)n_loc * d));
-    FLGP_TRY(dUall.alloc(sizeof(double) * (size_t)s * ucols));
-    FLGP_TRY(dHl.alloc(sizeof(double) * (size_t)n_loc * m));
-    // rows [lo, lo + n_loc) of every column of X_all
-    FLGP_HIP(hipMemcpy2DAsync(dX.p, sizeof(double) * (size_t)n_loc, X_all + lo, sizeof(double) * (size_t)n, sizeof(double) * (size_t)n_loc, d,
-                              hipMemcpyHostToDevice, st.s));
-    FLGP_TRY(h2d(dUall.p, U, sizeof(double) * (size_t)s * ucols, st.s));
-    {
-      InputCheck ck;
-      FLGP_TRY(ck.begin(st.s));
-      FLGP_TRY(ck.finite(st.s, dX.as<double>(), n_loc * d));
-      FLGP_TRY(ck.finite(st.s, dUall.as<double>(), (long)s * ucols));
-      FLGP_TRY(ck.verdict(st.s, "points / anchors"));
-    }
-    const double *sizes = (ucols == d + 1) ? dUall.as<double>() + (size_t)d * s : nullptr;
-    FLGP_TRY(flgp_dev_heat_kernel_covariance_sharded(st.s, comms[q], dX.as<double>(), (int)n_loc, (int)n_loc, d, (long)n, lo, dUall.as<double>(), s,
-                                                     s, sizes, m, r, t, K, kernel, gl, root, epsilon, dHl.as<double>(), (int)n_loc, nullptr,
-                                                     nullptr, 0, nullptr));
-    FLGP_HIP(hipMemcpy2DAsync(H + lo, sizeof(double) * (size_t)n, dHl.p, sizeof(double) * (size_t)n_loc, sizeof(double) * (size_t)n_loc, m,
-                              hipMemcpyDeviceToHost, st.s));
-    FLGP_HIP(hipStreamSynchronize(st.s));
-    return FLGP_OK;
+    if (q == fail_rank) { set_error("injected failure before the agreement (multi_test_fail_rank)"); return FLGP_ERR_HIP; }
+    return flgp_heat_kernel_covariance_rank(comms[q], X_all + lo, (long)n, (int)n_loc, (long)n, lo, m, d, U, s, ucols, r, t, K, kernel, gl,
+                                            root, epsilon, H + lo, (long)n, nullptr);
   };
   std::vector<std::thread> th;
   for (int q = 0; q < ndev; ++q)
@@ -1373,13 +1466,18 @@ extern "C" int flgp_heat_kernel_covariance_multi(const double *X_all, int n, int
       rcs[q] = rank_main(q);
       if (rcs[q] != FLGP_OK) {
         msgs[q] = flgp_last_error();
-        if (comms[q] && comms[q]->abort) comms[q]->abort(comms[q]->ctx);    // the others must not wait for this rank for ever
+        // the others must not wait for this rank for ever.  One process holds every rank's communicator, so ALL of them are
+        // aborted from here: with RCCL a peer's kernel only ends when its OWN communicator is aborted (ncclCommAbort).
+        // (FLGP_ERR_PEER = the ranks have agreed to leave together: nobody is waiting.)
+        if (rcs[q] != FLGP_ERR_PEER)
+          for (int c = 0; c < ndev; ++c) flgp_comm_abort(comms[c]);
       }
     });
   for (auto &x : th) x.join();
   for (auto c : comms) flgp_comm_destroy(c);
+  // report the rank that failed by itself before one that merely followed it out
   for (int q = 0; q < ndev; ++q)
-    if (rcs[q] != FLGP_OK && msgs[q].find("aborted by another rank") == std::string::npos) { set_error("rank %d: %s", q, msgs[q].c_str()); return rcs[q]; }
+    if (rcs[q] != FLGP_OK && rcs[q] != FLGP_ERR_PEER && msgs[q].find("aborted by") == std::string::npos) { set_error("rank %d: %s", q, msgs[q].c_str()); return rcs[q]; }
   for (int q = 0; q < ndev; ++q)
     if (rcs[q] != FLGP_OK) { set_error("rank %d: %s", q, msgs[q].c_str()); return rcs[q]; }
   return FLGP_OK;

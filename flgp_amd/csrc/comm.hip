@@ -19,6 +19,7 @@
 #include <condition_variable>
 #include <dlfcn.h>
 #include <mutex>
+#include <string>
 #include <vector>
 
 namespace flgp {
@@ -177,6 +178,7 @@ struct RcclApi {
   int (*CommInitRank)(rccl_comm_t *, int, rccl_uid, int) = nullptr;
   int (*CommInitAll)(rccl_comm_t *, int, const int *) = nullptr;
   int (*CommDestroy)(rccl_comm_t) = nullptr;
+  int (*CommAbort)(rccl_comm_t) = nullptr;       // optional: without it a failing rank cannot wake its peers
   int (*AllReduce)(const void *, void *, size_t, int, int, rccl_comm_t, hipStream_t) = nullptr;
   int (*AllGather)(const void *, void *, size_t, int, rccl_comm_t, hipStream_t) = nullptr;
   const char *(*GetErrorString)(int) = nullptr;
@@ -205,6 +207,7 @@ static int rccl_load() {
   a.CommInitRank = (int (*)(rccl_comm_t *, int, rccl_uid, int))dlsym(h, "ncclCommInitRank");
   a.CommInitAll = (int (*)(rccl_comm_t *, int, const int *))dlsym(h, "ncclCommInitAll");
   a.CommDestroy = (int (*)(rccl_comm_t))dlsym(h, "ncclCommDestroy");
+  a.CommAbort = (int (*)(rccl_comm_t))dlsym(h, "ncclCommAbort");
   a.AllReduce = (int (*)(const void *, void *, size_t, int, int, rccl_comm_t, hipStream_t))dlsym(h, "ncclAllReduce");
   a.AllGather = (int (*)(const void *, void *, size_t, int, rccl_comm_t, hipStream_t))dlsym(h, "ncclAllGather");
   a.GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
@@ -222,23 +225,42 @@ static int rccl_fail(int r, const char *what) {
   return FLGP_ERR_HIP;
 }
 
-struct RcclComm { rccl_comm_t comm = nullptr; };
+struct RcclComm {
+  rccl_comm_t comm = nullptr;
+  std::mutex mu;
+  bool aborted = false;       // ncclCommAbort has run: it frees the communicator, so no collective and no ncclCommDestroy after it
+};
 constexpr int RCCL_F64 = 8, RCCL_SUM = 0;      // ncclFloat64, ncclSum
 
 static int rccl_all_reduce(void *ctx, double *d_buf, size_t count, void *stream) {
   if (count == 0) return FLGP_OK;
-  const int r = g_rccl.AllReduce(d_buf, d_buf, count, RCCL_F64, RCCL_SUM, ((RcclComm *)ctx)->comm, (hipStream_t)stream);
+  RcclComm *c = (RcclComm *)ctx;
+  { std::lock_guard<std::mutex> lk(c->mu); if (c->aborted) { set_error("comm (RCCL): the communicator was aborted by a failing rank"); return FLGP_ERR_HIP; } }
+  const int r = g_rccl.AllReduce(d_buf, d_buf, count, RCCL_F64, RCCL_SUM, c->comm, (hipStream_t)stream);
   return r == 0 ? FLGP_OK : rccl_fail(r, "ncclAllReduce");
 }
 static int rccl_all_gather(void *ctx, const double *d_send, double *d_recv, size_t count, void *stream) {
   if (count == 0) return FLGP_OK;
-  const int r = g_rccl.AllGather(d_send, d_recv, count, RCCL_F64, ((RcclComm *)ctx)->comm, (hipStream_t)stream);
+  RcclComm *c = (RcclComm *)ctx;
+  { std::lock_guard<std::mutex> lk(c->mu); if (c->aborted) { set_error("comm (RCCL): the communicator was aborted by a failing rank"); return FLGP_ERR_HIP; } }
+  const int r = g_rccl.AllGather(d_send, d_recv, count, RCCL_F64, c->comm, (hipStream_t)stream);
   return r == 0 ? FLGP_OK : rccl_fail(r, "ncclAllGather");
+}
+// A rank that cannot join the next exchange: ncclCommAbort ends the communicator's kernels in flight (the peers' too once
+// THEIR communicators are aborted -- the single-process driver aborts all of them from the failing thread) and frees it.
+static void rccl_abort(void *ctx) {
+  RcclComm *c = (RcclComm *)ctx;
+  if (!c) return;
+  std::lock_guard<std::mutex> lk(c->mu);
+  if (c->aborted || !c->comm || !g_rccl.CommAbort) return;
+  c->aborted = true;
+  (void)g_rccl.CommAbort(c->comm);
+  c->comm = nullptr;
 }
 static void rccl_destroy(void *ctx) {
   RcclComm *c = (RcclComm *)ctx;
   if (!c) return;
-  if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+  if (c->comm && !c->aborted && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
   delete c;
 }
 
@@ -284,7 +306,8 @@ extern "C" int flgp_comm_rccl_init_rank(int world, int rank, const void *id128, 
   if (r != 0) { delete c; return rccl_fail(r, "ncclCommInitRank"); }
   flgp_comm *t = new flgp_comm();
   t->ctx = c; t->rank = rank; t->world = world;
-  t->all_reduce_sum = rccl_all_reduce; t->all_gather = rccl_all_gather; t->destroy = rccl_destroy; t->abort = nullptr;
+  t->all_reduce_sum = rccl_all_reduce; t->all_gather = rccl_all_gather; t->destroy = rccl_destroy;
+  t->abort = g_rccl.CommAbort ? rccl_abort : nullptr;
   *out = t;
   return FLGP_OK;
 }
@@ -300,7 +323,8 @@ extern "C" int flgp_comm_rccl_init_all(int ndev, const int *devices, flgp_comm *
     c->comm = comms[q];
     flgp_comm *t = new flgp_comm();
     t->ctx = c; t->rank = q; t->world = ndev;
-    t->all_reduce_sum = rccl_all_reduce; t->all_gather = rccl_all_gather; t->destroy = rccl_destroy; t->abort = nullptr;
+    t->all_reduce_sum = rccl_all_reduce; t->all_gather = rccl_all_gather; t->destroy = rccl_destroy;
+  t->abort = g_rccl.CommAbort ? rccl_abort : nullptr;
     out[q] = t;
   }
   return FLGP_OK;
@@ -326,5 +350,33 @@ extern "C" int flgp_comm_all_gather(const flgp_comm *c, const double *d_send, do
   FLGP_REQUIRE(c->all_gather, "comm: the table has no all_gather");
   return c->all_gather(c->ctx, d_send, d_recv, count, stream);
 }
+extern "C" void flgp_comm_abort(const flgp_comm *c) { if (c && c->abort) c->abort(c->ctx); }
+
+// Make a failure collective: every rank hands in its status (FLGP_OK or an error code) and every rank learns whether ANY
+// rank failed, through one all-reduce of a flag on the communicator itself -- so that a rank whose own rows are bad (NaN in
+// its shard, an allocation that failed) does not leave the others waiting in the next exchange.  Returns my_status if it is
+// an error, FLGP_ERR_PEER if only other ranks failed, FLGP_OK if none did.  Synchronises the stream.
+extern "C" int flgp_comm_agree(const flgp_comm *c, int my_status, void *stream) {
+  if (!c || c->world <= 1) return my_status;
+  hipStream_t st = (hipStream_t)stream;
+  DevBuf flag;
+  double h[2] = {my_status != FLGP_OK ? 1.0 : 0.0, 1.0};     // [failures, ranks that answered]
+  int rc = flag.alloc(sizeof(h));
+  if (rc == FLGP_OK && hipMemcpyAsync(flag.p, h, sizeof(h), hipMemcpyHostToDevice, st) != hipSuccess) rc = FLGP_ERR_HIP;
+  if (rc == FLGP_OK && hipStreamSynchronize(st) != hipSuccess) rc = FLGP_ERR_HIP;      // (h is a stack variable)
+  if (rc != FLGP_OK) {                   // this rank cannot even take part: wake the others the hard way
+    if (c->abort) c->abort(c->ctx);
+    return my_status != FLGP_OK ? my_status : rc;
+  }
+  std::string mine = my_status != FLGP_OK ? flgp_last_error() : "";
+  FLGP_REQUIRE(c->all_reduce_sum, "comm: the table has no all_reduce_sum");
+  rc = c->all_reduce_sum(c->ctx, flag.as<double>(), 2, stream);
+  if (rc == FLGP_OK && (hipMemcpyAsync(h, flag.p, sizeof(h), hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)) rc = FLGP_ERR_HIP;
+  if (my_status != FLGP_OK) { set_error("%s", mine.c_str()); return my_status; }
+  if (rc != FLGP_OK) return rc;
+  if (h[0] > 0.0) { set_error("comm: %d of %d ranks failed before the exchange (this rank did not); all ranks leave together", (int)h[0], (int)h[1]); return FLGP_ERR_PEER; }
+  return FLGP_OK;
+}
+
 extern "C" int flgp_comm_rank(const flgp_comm *c) { return c ? c->rank : 0; }
 extern "C" int flgp_comm_world(const flgp_comm *c) { return c ? c->world : 1; }

@@ -65,7 +65,17 @@ struct DevBuf {
   void release() {
     if (p && owned) {
       bool kept = false;
-      if (cap && dev >= 0) { (void)hipDeviceSynchronize(); kept = pool_give(dev, p, cap); }
+      if (cap && dev >= 0) {
+        // the hipFree this replaces waited for the OWNING device; the caller may be on another one by now (a rank's thread of
+        // the multi-GPU entry, a flgp_set_device in between)
+        int cur = -1;
+        const bool here = hipGetDevice(&cur) == hipSuccess && cur == dev;
+        if (here || hipSetDevice(dev) == hipSuccess) {
+          (void)hipDeviceSynchronize();
+          kept = pool_give(dev, p, cap);
+          if (!here && cur >= 0) (void)hipSetDevice(cur);
+        }
+      }
       if (!kept) (void)hipFree(p);
     }
     p = nullptr; cap = 0; dev = -1;
@@ -82,6 +92,10 @@ struct DevBuf {
       if (p) { cap = bytes; dev = d; return FLGP_OK; }
     }
     hipError_t e = hipMalloc(&p, bytes);
+    if (e != hipSuccess) {       // the memory may be parked in the cache under other sizes: empty it and ask once more
+      (void)hipGetLastError();
+      if (flgp_dev_pool_release() > 0) e = hipMalloc(&p, bytes);
+    }
     if (e != hipSuccess) { p = nullptr; set_error("hipMalloc of %zu bytes failed: %s", bytes, hipGetErrorString(e)); return FLGP_ERR_NOMEM; }
     if (bytes <= ((size_t)4 << 30)) { cap = bytes; dev = d; }
     return FLGP_OK;

@@ -1341,10 +1341,106 @@ def test_sharded_covariance_behind_the_c_abi(oracle, devices):
         api.heat_kernel_covariance_cpp(X[:m], X[m:], s, s + 1, t, K, models, 1, 0.7, U=U, devices=devices)
 
 
+def test_one_bad_shard_fails_every_rank_together(oracle):
+    """A failure on ONE rank of the sharded host entry must come back from EVERY rank, not hang the others in their next
+    exchange (the reference, src/Spectrum.cpp:28-43, is one process and cannot hang).  (1) A NaN in rank 1's rows only:
+    the ranks agree after the input check (flgp_comm_agree: one 16-byte all-reduce), rank 1 reports the NaN, rank 0 leaves
+    with it.  (2) A rank that leaves without a word before the agreement (test hook multi_test_fail_rank: what a failed
+    hipSetDevice looks like): the failing thread aborts every communicator and the peer that waits in the agreement
+    returns.  (3) The library is usable afterwards and gives the clean answer."""
+    import time
+    n, d, s, r, K, m, t = 6000, 5, 200, 5, 30, 100, 4.0
+    X, U0, U = make_case(n, d, s, r, seed=123)
+    models = dict(kernel="lae", gl="cluster-normalized", root=True)
+    Xbad = X.copy()
+    Xbad[n - 7, 2] = np.nan                                  # in the second rank's block (rows [3000, 6000))
+    t0 = time.time()
+    with pytest.raises(api.FlgpError, match="NaN"):
+        api.heat_kernel_covariance_cpp(Xbad[:m], Xbad[m:], s, r, t, K, models, 1, 0.1, U=U, devices=[0, 0])
+    with pytest.raises(api.FlgpError, match="NaN"):
+        api.heat_kernel_covariance_cpp(Xbad[:m], Xbad[m:], s, r, t, K, models, 1, 0.1, U=U, devices=[0, 0, 0])
+    L = _lib.lib()
+    for bad_rank in (0, 1):
+        L.flgp_set_tuning(b"multi_test_fail_rank", bad_rank)
+        try:
+            with pytest.raises(api.FlgpError, match="injected failure"):
+                api.heat_kernel_covariance_cpp(X[:m], X[m:], s, r, t, K, models, 1, 0.1, U=U, devices=[0, 0])
+        finally:
+            L.flgp_set_tuning(b"multi_test_fail_rank", -1)
+    assert time.time() - t0 < 60.0
+    H1 = api.heat_kernel_covariance_cpp(X[:m], X[m:], s, r, t, K, models, 1, 0.1, U=U)
+    Hm = api.heat_kernel_covariance_cpp(X[:m], X[m:], s, r, t, K, models, 1, 0.1, U=U, devices=[0, 0])
+    assert np.abs(Hm - H1).max() <= H_RTOL * np.abs(H1).max()
+
+
+def test_c4_full_size_through_the_c_sharded_entry():
+    """BASELINE configs[3] (C4) at n = 1e6 through the entry `bench.py --gpus N` drives -- flgp_dev_heat_kernel_covariance_sharded
+    with a flgp_comm (here the in-process transport, two ranks = two host threads on the one card; on the 8-GPU node the same
+    call sites run over RCCL) -- against the same entry on one rank: eigenvalues 1e-10, H on the training block and 8192
+    sampled rows 1e-8 of max|H|.  (test_c4_full_size_row_sharded_two_ranks covers the Python driver over gloo.)"""
+    from flgp_amd.pipeline import shard_bounds
+    L = _lib.lib()
+    n, d, s, r, K, m, t = 1_000_000, 16, 5000, 10, 200, 1000, 10.0
+    rng = np.random.default_rng(4)
+    sample = np.sort(np.concatenate([np.arange(1000), 1000 + rng.choice(n - 1000, 8192, replace=False)]))
+    sel = np.sort(synth.random_anchor_rows(n, s))
+
+    def run(world):
+        comms = (ctypes.c_void_p * world)()
+        _lib.check(L.flgp_comm_inproc_create(world, comms))
+
+        def body(q):
+            st = torch.cuda.current_stream().cuda_stream
+            lo, hi = shard_bounds(n, world, q)
+            Xh = synth.gaussian_mixture(hi - lo, d, row_offset=lo)
+            dX = cm(Xh)
+            mine = sel[(sel >= lo) & (sel < hi)] - lo
+            Ul = cm(Xh[mine])
+            U = torch.empty((d, s), dtype=torch.float64, device="cuda:0")
+            _lib.check(L.flgp_dev_gather_anchors(st, comms[q], Ul.data_ptr(), len(mine), d, U.data_ptr(), s))
+            sizes = torch.empty(s, dtype=torch.float64, device="cuda:0")
+            _lib.check(L.flgp_dev_cluster_sizes(st, comms[q], dX.data_ptr(), hi - lo, hi - lo, d, U.data_ptr(), s, s, sizes.data_ptr()))
+            H = torch.empty((m, hi - lo), dtype=torch.float64, device="cuda:0")
+            vals = torch.empty(K, dtype=torch.float64, device="cuda:0")
+            _lib.check(L.flgp_dev_heat_kernel_covariance_sharded(st, comms[q], dX.data_ptr(), hi - lo, hi - lo, d, n, lo, U.data_ptr(), s, s,
+                                                                 sizes.data_ptr(), m, r, t, K, b"lae", b"cluster-normalized", 1, 0.1,
+                                                                 H.data_ptr(), hi - lo, vals.data_ptr(), None, 0, None))
+            loc = sample[(sample >= lo) & (sample < hi)] - lo
+            return H[:, torch.from_numpy(loc).cuda()].T.contiguous().cpu().numpy(), vals.cpu().numpy()
+
+        try:
+            res = _run_ranks(world, body)
+        finally:
+            for q in range(world):
+                L.flgp_comm_destroy(comms[q])
+        return np.vstack([x[0] for x in res]), [x[1] for x in res]
+
+    H1, v1 = run(1)
+    torch.cuda.empty_cache()
+    H2, v2 = run(2)
+    assert H1.shape == H2.shape == (sample.size, m)
+    assert np.abs(H1 - H2).max() <= H_RTOL * np.abs(H1).max(), np.abs(H1 - H2).max() / np.abs(H1).max()
+    for q in range(2):
+        np.testing.assert_allclose(v2[q], v1[0], rtol=EIG_RTOL)
+    assert abs(v1[0][0] - 1.0) < 1e-6
+
+
+class _CommTable(ctypes.Structure):
+    """struct flgp_comm (include/flgp_hip.h): the table a transport fills in."""
+    _fields_ = [("ctx", ctypes.c_void_p), ("rank", ctypes.c_int), ("world", ctypes.c_int),
+                ("all_reduce_sum", ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)),
+                ("all_gather", ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p)),
+                ("destroy", ctypes.CFUNCTYPE(None, ctypes.c_void_p)),
+                ("abort", ctypes.CFUNCTYPE(None, ctypes.c_void_p))]
+
+
 def test_rccl_backend_loads_and_runs_on_one_rank(stages):
     """The RCCL backend (librccl.so through dlopen) with a world of one -- all a one-GPU box can hold, RCCL refuses two
-    ranks on one device: communicator creation, both collectives (identities on one rank) and the sharded device entry
-    point on top of it, against the stage-by-stage driver."""
+    ranks on one device.  The convenience wrappers return before the table when world <= 1, so the TABLE's entries are
+    called directly here: ncclAllReduce / ncclAllGather execute through the restated prototypes of csrc/comm.hip (sum over
+    one rank = identity, gather of one rank = copy), ncclCommAbort is loaded and installed as the abort hook (and used on a
+    second communicator: collectives afterwards are refused, destroy does not touch the freed handle); then the sharded
+    device entry point on top of the communicator, against the stage-by-stage driver."""
     L = _lib.lib()
     comms = (ctypes.c_void_p * 1)()
     dev = (ctypes.c_int * 1)(0)
@@ -1353,13 +1449,27 @@ def test_rccl_backend_loads_and_runs_on_one_rank(stages):
     _lib.check(L.flgp_comm_rccl_unique_id(idbuf))
     try:
         st = torch.cuda.current_stream().cuda_stream
-        x = torch.arange(1000, dtype=torch.float64, device="cuda:0")
+        tab = ctypes.cast(comms[0], ctypes.POINTER(_CommTable)).contents
+        assert tab.rank == 0 and tab.world == 1 and tab.all_reduce_sum and tab.all_gather
+        assert tab.abort, "ncclCommAbort was not found in librccl.so: a failing rank could not wake its peers"
+        x = torch.arange(1000, dtype=torch.float64, device="cuda:0") * 0.25
+        assert tab.all_reduce_sum(tab.ctx, x.data_ptr(), 1000, st) == 0, L.flgp_last_error()        # -> ncclAllReduce
+        y = torch.full((1000,), -1.0, dtype=torch.float64, device="cuda:0")
+        assert tab.all_gather(tab.ctx, x.data_ptr(), y.data_ptr(), 1000, st) == 0, L.flgp_last_error()   # -> ncclAllGather
+        torch.cuda.synchronize()
+        np.testing.assert_array_equal(x.cpu().numpy(), np.arange(1000.0) * 0.25)
+        np.testing.assert_array_equal(y.cpu().numpy(), np.arange(1000.0) * 0.25)
+        assert L.flgp_comm_agree(comms[0], 0, st) == 0 and L.flgp_comm_agree(comms[0], -2, st) == -2     # one rank: its own status
+        # abort on a second communicator: refused afterwards, destroyed without touching the freed handle
+        c2 = (ctypes.c_void_p * 1)()
+        _lib.check(L.flgp_comm_rccl_init_all(1, dev, c2))
+        t2 = ctypes.cast(c2[0], ctypes.POINTER(_CommTable)).contents
+        L.flgp_comm_abort(c2[0])
+        assert t2.all_reduce_sum(t2.ctx, x.data_ptr(), 1000, st) != 0
+        L.flgp_comm_destroy(c2[0])
         _lib.check(L.flgp_comm_all_reduce_sum(comms[0], x.data_ptr(), 1000, st))
-        y = torch.empty(1000, dtype=torch.float64, device="cuda:0")
         _lib.check(L.flgp_comm_all_gather(comms[0], x.data_ptr(), y.data_ptr(), 1000, st))
         torch.cuda.synchronize()
-        np.testing.assert_array_equal(x.cpu().numpy(), np.arange(1000.0))
-        np.testing.assert_array_equal(y.cpu().numpy(), np.arange(1000.0))
         n, d, s, r, K, m, t = 5000, 4, 256, 5, 32, 200, 3.0
         X, U0, U = make_case(n, d, s, r, seed=5)
         dX = cm(X); dU = cm(U0); sizes = torch.from_numpy(U[:, d].copy()).cuda()
