@@ -321,6 +321,38 @@ def main():
         except Exception as e:  # pragma: no cover
             out["t_e2e_ms"] = None
             out["t_e2e_note"] = "failed: %r" % (e,)
+    rehearse_rank_e2e = world == 1 and os.environ.get("FLGP_BENCH_E2E_RANK") == "1"     # one-GPU box: the same code with a NULL communicator
+    if ((world > 1 and comm is not None) or rehearse_rank_e2e) and not args.no_e2e:
+        # N > 1 at the host boundary: every rank hands its rows of X over as host memory and gets its rows of H back
+        # (flgp_heat_kernel_covariance_rank: upload, agreement, sharded path, pinned pipelined copy) -- each rank has its
+        # own PCIe link, so this is the number that should scale with N.  MAX over ranks, best of 3; never part of `value`.
+        try:
+            res = None
+            torch.cuda.empty_cache()
+            U_h = np.asfortranarray(np.column_stack([np.ascontiguousarray(U.t().cpu().numpy()), num_class.cpu().numpy()]))
+            X_h = np.asfortranarray(X_np)
+            H_h = np.empty((n_loc, args.m), order="F")
+            best = None
+            for _ in range(3):
+                barrier()
+                t0 = time.perf_counter()
+                rc = L.flgp_heat_kernel_covariance_rank(comm, X_h.ctypes.data, n_loc, n_loc, n, lo, args.m, d, U_h.ctypes.data, s, d + 1,
+                                                        args.r, args.t, args.K, b"lae", b"cluster-normalized", 1, 0.1,
+                                                        H_h.ctypes.data, n_loc, None)
+                barrier()
+                tt = torch.tensor([(time.perf_counter() - t0) * 1e3, float(rc != 0)], dtype=torch.float64, device=device)
+                if world > 1:
+                    torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)      # (every rank learns of a failure: no rank raises alone)
+                if tt[1].item() != 0.0:
+                    raise RuntimeError("a rank failed: " + (L.flgp_last_error().decode("utf-8", "replace") if rc else "another rank"))
+                best = float(tt[0].item()) if best is None else min(best, float(tt[0].item()))
+            out["t_e2e_rank_ms" if rehearse_rank_e2e else "t_e2e_ms"] = best
+            out["t_e2e_rank_note" if rehearse_rank_e2e else "t_e2e_note"] = ("flgp_heat_kernel_covariance_rank on every rank, host pointers in / out (per rank: X %.0f MB up, H %.2f GB "
+                                 "down through the pinned ring), max over ranks, best of 3 calls" % (X_h.nbytes / 1e6, H_h.nbytes / 1e9))
+            del H_h
+        except Exception as e:  # pragma: no cover
+            out["t_e2e_ms"] = None
+            out["t_e2e_note"] = "failed: %r" % (e,)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         nc = min(args.cpu_rows, n_loc)
         U_np = np.ascontiguousarray(U.t().cpu().numpy())
