@@ -164,6 +164,44 @@ static SEXP subsample(SEXP X, int s, const char *method, int nstart) {
   return R_NilValue;
 }
 
+/* Rcpp::RNGScope (src/RcppExports.cpp:19): GetRNGstate() ... PutRNGstate() around everything that may draw from R's RNG.
+ * subsample() can leave by longjmp (Rf_error here, or an R-level error inside stats::kmeans / ClusterR), and Rcpp's scope
+ * object is unwound in that case; in C the same is R_UnwindProtect, whose clean-up function runs on both ways out. */
+struct sub_args { SEXP X; int s; const char *method; int nstart; };
+static SEXP sub_body(void *p) {
+  struct sub_args *a = (struct sub_args *)p;
+  return subsample(a->X, a->s, a->method, a->nstart);
+}
+static void sub_clean(void *p, Rboolean jump) { (void)p; (void)jump; PutRNGstate(); }
+static SEXP subsample_rng(SEXP X, int s, const char *method, int nstart) {
+  struct sub_args a = {X, s, method, nstart};
+  SEXP cont = PROTECT(R_MakeUnwindCont());
+  GetRNGstate();
+  SEXP U = R_UnwindProtect(sub_body, &a, sub_clean, NULL, cont);
+  UNPROTECT(1);
+  return U;
+}
+
+/* FLGP_DEVICES="0,1,2,3" in the environment of the R session: the GPUs the rows are sharded over (one host thread each
+ * inside the library, RCCL over xGMI between them); a single id selects that GPU; unset: the current device.  A list that
+ * is not a comma-separated sequence of non-negative integers is an error, not a silent fall-back to one GPU. */
+static int devices_from_env(int *devs, int cap) {
+  const char *env = getenv("FLGP_DEVICES");
+  int ndev = 0;
+  if (!env || !*env) return 0;
+  for (;;) {
+    char *end = NULL;
+    const long v = strtol(env, &end, 10);
+    if (end == env || v < 0 || v > 4096) Rf_error("FLGP_DEVICES=\"%s\" is not a comma-separated list of device numbers", getenv("FLGP_DEVICES"));
+    if (ndev == cap) Rf_error("FLGP_DEVICES lists more than %d devices", cap);
+    devs[ndev++] = (int)v;
+    if (*end == 0) break;
+    if (*end != ',') Rf_error("FLGP_DEVICES=\"%s\" is not a comma-separated list of device numbers", getenv("FLGP_DEVICES"));
+    env = end + 1;
+  }
+  return ndev;
+}
+
 static void sort_row(int *j, double *x, int r) { /* ascending column index inside a row */
   for (int a = 1; a < r; ++a) {
     int tj = j[a];
@@ -178,7 +216,7 @@ static void sort_row(int *j, double *x, int r) { /* ascending column index insid
 /* ---- _FLGP_subsample_cpp (4 args, src/RcppExports.cpp:361-372) ---- */
 SEXP FLGP_subsample_cpp(SEXP XS, SEXP sS, SEXP methodS, SEXP nstartS) {
   SEXP X = PROTECT(as_real_matrix(XS, "X"));
-  SEXP U = subsample(X, Rf_asInteger(sS), as_cstr(methodS), Rf_asInteger(nstartS));
+  SEXP U = subsample_rng(X, Rf_asInteger(sS), as_cstr(methodS), Rf_asInteger(nstartS));
   UNPROTECT(1);
   return U;
 }
@@ -292,22 +330,11 @@ SEXP FLGP_heat_kernel_covariance_cpp(SEXP XS, SEXP XnewS, SEXP sS, SEXP rS, SEXP
     memcpy(REAL(Xall) + (size_t)k * n, REAL(X) + (size_t)k * m, sizeof(double) * (size_t)m);
     memcpy(REAL(Xall) + (size_t)k * n + m, REAL(Xnew) + (size_t)k * mnew, sizeof(double) * (size_t)mnew);
   }
-  GetRNGstate(); /* Rcpp::RNGScope: subsample="random" draws from R's RNG */
-  SEXP U = PROTECT(subsample(Xall, s, as_cstr(list_get(modelsS, "subsample")), Rf_asInteger(nstartS)));
-  PutRNGstate();
+  int devs[16];
+  const int ndev = devices_from_env(devs, 16);       /* (before anything is drawn or computed: a malformed list is an error) */
+  SEXP U = PROTECT(subsample_rng(Xall, s, as_cstr(list_get(modelsS, "subsample")), Rf_asInteger(nstartS)));
   SEXP H = PROTECT(Rf_allocMatrix(REALSXP, n, m));
-  /* FLGP_DEVICES="0,1,2,3" in the environment of the R session: the rows are sharded over those GPUs (one host thread
-   * each inside the library, RCCL over xGMI between them); unset or a single id: the one-GPU entry point */
-  int devs[16], ndev = 0;
-  const char *env = getenv("FLGP_DEVICES");
-  while (env && *env && ndev < 16) {
-    char *end = NULL;
-    const long v = strtol(env, &end, 10);
-    if (end == env) break;
-    devs[ndev++] = (int)v;
-    env = (*end == ',') ? end + 1 : end;
-  }
-  if (ndev > 1)
+  if (ndev >= 1)       /* (one id: the library switches to that GPU for the call and back) */
     chk(flgp_heat_kernel_covariance_multi(REAL(Xall), n, m, d, REAL(U), s, Rf_ncols(U), r, Rf_asReal(tS), K,
                                           as_cstr(list_get(modelsS, "kernel")), as_cstr(list_get(modelsS, "gl")),
                                           Rf_asLogical(list_get(modelsS, "root")), Rf_asReal(epsilonS), ndev, devs, REAL(H)));
@@ -323,9 +350,7 @@ SEXP FLGP_heat_kernel_covariance_cpp(SEXP XS, SEXP XnewS, SEXP sS, SEXP rS, SEXP
 SEXP FLGP_lae_eigenmap(SEXP XS, SEXP sS, SEXP rS, SEXP ndimS, SEXP subsampleS, SEXP normS, SEXP nstartS) {
   SEXP X = PROTECT(as_real_matrix(XS, "X"));
   const int n = Rf_nrows(X), d = Rf_ncols(X), s = Rf_asInteger(sS), ndim = Rf_asInteger(ndimS);
-  GetRNGstate();
-  SEXP U = PROTECT(subsample(X, s, as_cstr(subsampleS), Rf_asInteger(nstartS)));
-  PutRNGstate();
+  SEXP U = PROTECT(subsample_rng(X, s, as_cstr(subsampleS), Rf_asInteger(nstartS)));
   SEXP ev = PROTECT(Rf_allocVector(REALSXP, ndim));
   SEXP vec = PROTECT(Rf_allocMatrix(REALSXP, n, ndim));
   chk(flgp_lae_eigenmap(REAL(X), n, d, REAL(U), s, Rf_ncols(U), Rf_asInteger(rS), ndim, as_cstr(normS), REAL(ev), REAL(vec)));

@@ -1,6 +1,7 @@
 /* Test double: declarations of the handful of R C-API entry points flgp_rcall.c uses, written
- * from R's documented API ("Writing R Extensions", sections 5.9-5.10) so that the shim can be
- * syntax- and type-checked in an image without R.  NOT R's header; nothing links against it. */
+ * from R's documented API ("Writing R Extensions", sections 5.9-5.10, 6.12) so that the shim can be
+ * type-checked AND executed (rmock.c in this directory implements them) in an image without R.
+ * NOT R's header. */
 #ifndef FLGP_R_MOCK_RINTERNALS_H
 #define FLGP_R_MOCK_RINTERNALS_H
 #include <stddef.h>
@@ -9,6 +10,7 @@ typedef ptrdiff_t R_xlen_t;
 typedef int Rboolean;
 #define FALSE 0
 #define TRUE 1
+#define LGLSXP 10
 #define INTSXP 13
 #define REALSXP 14
 #define STRSXP 16
@@ -58,4 +60,8 @@ char *R_alloc(size_t, int);
 void GetRNGstate(void);
 void PutRNGstate(void);
 double unif_rand(void);            /* R_ext/Random.h (pulled in by R.h) */
+/* unwind protection (R >= 3.5.0, "Writing R Extensions" 6.12): cleanfun runs whether fun returns or jumps */
+SEXP R_MakeUnwindCont(void);
+void R_ContinueUnwind(SEXP cont) __attribute__((noreturn));
+SEXP R_UnwindProtect(SEXP (*fun)(void *data), void *data, void (*cleanfun)(void *data, Rboolean jump), void *cleandata, SEXP cont);
 #endif
