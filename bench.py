@@ -49,6 +49,10 @@ def parse():
     ap.add_argument("--t", type=float, default=10.0)
     ap.add_argument("--cpu-rows", type=int, default=100000, help="rows of the bounded CPU-baseline sample (BASELINE.md: an n = 1e5 slice)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--workload", choices=["lae", "se_grid"], default="lae",
+                    help="lae: the headline path (BASELINE configs[2], the metric of BASELINE.json).  se_grid: the spectrum part of "
+                         "fit_se_*_gp (src/Fit.cpp:127-178) at the same size -- one k-NN with distances, then TEN spectra for the "
+                         "bandwidths a2s = exp(seq(log 0.1, log 10, length 10)) of R/Fit.R:128-130; a second JSON line of its own, N = 1 only")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--tune", action="append", default=[], help="key=value tuning knobs (experiments)")
     ap.add_argument("--no-kernel-events", action="store_true", help="do not record per-kernel HIP events (no roofline object)")
@@ -206,6 +210,43 @@ def main():
         if world > 1:
             torch.distributed.barrier()
         torch.cuda.synchronize(device)
+
+    if args.workload == "se_grid":
+        if world != 1:
+            raise SystemExit("--workload se_grid is a one-GPU measurement")
+        a2s = np.exp(np.linspace(np.log(0.1), np.log(10.0), 10))
+        vals = torch.empty((10, args.K), dtype=torch.float64, device=device)
+        iters = (ctypes.c_int * 10)()
+        mean = ctypes.c_double(0.0)
+
+        def grid(par):
+            _lib.check(L.flgp_dev_se_spectrum_grid(torch.cuda.current_stream(device).cuda_stream, X_loc.data_ptr(), n, n, d, U.data_ptr(), s, s,
+                                                   num_class.data_ptr(), args.r, args.K, a2s.ctypes.data, 10, b"cluster-normalized", 1,
+                                                   vals.data_ptr(), None, ctypes.addressof(mean), par, ctypes.addressof(iters)))
+        res_t = {}
+        for par in (10, 1):                 # ten spectra at once (one host thread + stream each) vs one after the other
+            for _ in range(max(1, args.warmup)):
+                grid(par)
+            torch.cuda.synchronize(device)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                grid(par)
+            torch.cuda.synchronize(device)
+            res_t[par] = (time.perf_counter() - t0) * 1e3 / args.steps
+        out = {
+            "metric": "points/sec through k-NN(with distances) -> 10 x [SE weights -> Laplacian -> trunc-SVD -> U] (fit_se_* bandwidth grid), n=1e6 d=16 K=200",
+            "value": n / (res_t[10] * 1e-3), "unit": "points/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": res_t[10], "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"SE bandwidth grid, Gaussian-mixture n={n} d={d} s={s} r={args.r} K={args.K}, ten bandwidths a2 = 0.1..10 "
+                                   f"(R/Fit.R:128-130), gl=cluster-normalized root=TRUE; eigenvectors (n x K per bandwidth) computed and left in HBM",
+                       "spectra_in_flight": 10, "outer_iterations_per_bandwidth": [int(x) for x in iters],
+                       "distances_mean": mean.value, "values_top_K_th": [[float(vals[i, 0]), float(vals[i, args.K - 1])] for i in range(10)]},
+            "ms_per_step_sequential": res_t[1],
+            "note": "ms_per_step: the ten spectra run concurrently (flgp_dev_se_spectrum_grid, max_parallel = 10); ms_per_step_sequential: one "
+                    "after the other (max_parallel = 1).  Not the BASELINE.json metric: no roofline / cpu_baseline objects on this line.",
+        }
+        print(json.dumps(out))
+        return
 
     class _CRes:
         stage_ms = {}

@@ -64,6 +64,8 @@ _SIGNATURES = {
                                             c_char_p, c_char_p, c_int, c_double, P]),
     "flgp_se_spectrum_grid": (c_int, [P, c_int, c_int, P, c_int, c_int, c_int, c_int, P, c_int, c_char_p, c_int, P, P, P, c_int]),
     "flgp_lae_eigenmap": (c_int, [P, c_int, c_int, P, c_int, c_int, c_int, c_int, c_char_p, P, P]),
+    "flgp_dev_se_spectrum_grid": (c_int, [P, P, c_int, c_int, c_int, P, c_int, c_int, P, c_int, c_int, P, c_int, c_char_p, c_int, P, P, P,
+                                          c_int, P]),
     # device-pointer stage entry points
     "flgp_dev_anchor_dpad": (c_int, [c_int]),
     "flgp_dev_anchor_rows": (c_int, [c_int]),

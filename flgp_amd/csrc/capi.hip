@@ -1502,35 +1502,31 @@ extern "C" int flgp_lae_eigenmap(const double *X, int n, int d, const double *U,
 // thread + one HIP stream each (the small dense eigen-kernels of one solve occupy a few CUs only).
 // values: l x K (row i = bandwidth i), vectors: l blocks of n x K column-major.
 // ---------------------------------------------------------------------------------------------
-extern "C" int flgp_se_spectrum_grid(const double *X_all, int n, int d, const double *U, int s, int ucols, int r,
-                                     int K, const double *a2s, int l, const char *gl, int root, double *values,
-                                     double *vectors, double *distances_mean_out, int max_parallel) {
-  const int glc = flgp_parse_gl(gl);
-  if (glc < 0) return glc;
-  FLGP_REQUIRE(a2s && l >= 1 && values && vectors, "se_spectrum_grid: bad arguments");
-  if (K < 0) K = s;
-  FLGP_REQUIRE(K >= 1 && K <= s, "need 1 <= K <= s (K=%d, s=%d)", K, s);
-  Stream st;
-  FLGP_TRY(st.create());
-  Sim S;
-  FLGP_TRY(upload_points(S, st.s, X_all, n, d, U, s, ucols, glc == FLGP_GL_CLUSTER_NORMALIZED));
-  FLGP_TRY(run_knn(S, st.s, r, true));
+// The grid on data that is already on the device (S: points, anchors, anchor panel): one k-NN with distances, one shared
+// pattern, then l spectra, `max_parallel` of them at a time on their own host thread + stream.  Results go to the host
+// (values / vectors non-NULL: the reference's EigenPair per bandwidth) and / or stay on the device (d_values l x K,
+// d_vectors l blocks of n x K; either may be NULL -- bench.py times the ten spectra without moving 16 GB of vectors).
+static int se_grid_core(Sim &S, hipStream_t st0, int r, int K, const double *a2s, int l, int glc, int root, const double *sizes,
+                        double *values, double *vectors, double *d_values, double *d_vectors, double *distances_mean_out,
+                        int max_parallel, int *iters_out) {
+  const int n = S.n, d = S.d, s = S.s;
+  FLGP_TRY(run_knn(S, st0, r, true));
   FLGP_TRY(alloc_ell(S));
   // pattern (sorted by column) and the mean distance; the weights of this first call are discarded
-  FLGP_TRY(flgp_dev_se_weights_den(st.s, S.knn_idx.as<int>(), S.knn_dist.as<double>(), n, n, r, 1.0, S.ell_idx.as<int>(),
+  FLGP_TRY(flgp_dev_se_weights_den(st0, S.knn_idx.as<int>(), S.knn_dist.as<double>(), n, n, r, 1.0, S.ell_idx.as<int>(),
                                    S.ell_val.as<double>()));
-  FLGP_TRY(build_csc(S, st.s));
+  FLGP_TRY(build_csc(S, st0));
   DevBuf dmean, mwork;
   FLGP_TRY(dmean.alloc(sizeof(double)));
   FLGP_TRY(mwork.alloc(sizeof(double) * (size_t)(((long)n * r + 4095) / 4096 + 1)));
-  FLGP_TRY(flgp_dev_mean(st.s, S.knn_dist.as<double>(), (long)n * r, dmean.as<double>(), mwork.as<double>()));
+  FLGP_TRY(flgp_dev_mean(st0, S.knn_dist.as<double>(), (long)n * r, dmean.as<double>(), mwork.as<double>()));
   double mean = 0.0;
-  FLGP_TRY(d2h(&mean, dmean.p, sizeof(double), st.s));
-  FLGP_HIP(hipStreamSynchronize(st.s));
+  FLGP_TRY(d2h(&mean, dmean.p, sizeof(double), st0));
+  FLGP_HIP(hipStreamSynchronize(st0));
   if (distances_mean_out) *distances_mean_out = mean;
-  const double *sizes = (ucols == d + 1) ? S.U.as<double>() + (size_t)d * s : nullptr;
   int dev = 0;
   FLGP_HIP(hipGetDevice(&dev));
+  (void)d;
 
   std::vector<int> rcs(l, FLGP_OK);
   std::vector<std::string> msgs(l);
@@ -1539,7 +1535,7 @@ extern "C" int flgp_se_spectrum_grid(const double *X_all, int n, int d, const do
     Stream ws;
     FLGP_TRY(ws.create());
     Sim W;   // shares pattern / CSC with S, owns its values
-    W.n = n; W.d = d; W.s = s; W.r = r;
+    W.n = n; W.d = S.d; W.s = s; W.r = r;
     FLGP_TRY(W.ell_val.alloc(sizeof(double) * (size_t)n * r));
     DevBuf scratch_idx;
     FLGP_TRY(scratch_idx.alloc(sizeof(int) * (size_t)n * r));
@@ -1564,14 +1560,16 @@ extern "C" int flgp_se_spectrum_grid(const double *X_all, int n, int d, const do
     FLGP_TRY(V.alloc(sizeof(double) * (size_t)s * K));
     int solve_info[4] = {0, 0, 0, 0};
     FLGP_TRY(flgp_dev_eig_topk(ws.s, G.as<double>(), s, s, K, 0.0, eig.as<double>(), V.as<double>(), s, ework.p, wb, solve_info));
+    if (iters_out) iters_out[i] = solve_info[0];
     FLGP_TRY(flgp_dev_spectrum_usable_route(ws.s, eig.as<double>(), K, solve_info[2]));   // (a bandwidth that underflows a column of Z ends here, with the message)
-    FLGP_TRY(vals.alloc(sizeof(double) * (size_t)K));
-    FLGP_TRY(vecs.alloc(sizeof(double) * (size_t)n * K));
+    double *vals_p = d_values ? d_values + (size_t)i * K : nullptr, *vecs_p = d_vectors ? d_vectors + (size_t)i * n * K : nullptr;
+    if (!vals_p) { FLGP_TRY(vals.alloc(sizeof(double) * (size_t)K)); vals_p = vals.as<double>(); }
+    if (!vecs_p) { FLGP_TRY(vecs.alloc(sizeof(double) * (size_t)n * K)); vecs_p = vecs.as<double>(); }
     FLGP_TRY(uwork.alloc(flgp_dev_u_recover_workspace(s, K)));
     FLGP_TRY(flgp_dev_u_recover(ws.s, eidx, W.ell_val.as<double>(), n, r, V.as<double>(), s, s, eig.as<double>(), K,
-                                std::sqrt((double)n), root, vecs.as<double>(), n, vals.as<double>(), uwork.as<double>()));
-    FLGP_TRY(d2h(values + (size_t)i * K, vals.p, sizeof(double) * (size_t)K, ws.s));
-    FLGP_TRY(d2h(vectors + (size_t)i * n * K, vecs.p, sizeof(double) * (size_t)n * K, ws.s));
+                                std::sqrt((double)n), root, vecs_p, n, vals_p, uwork.as<double>()));
+    if (values) FLGP_TRY(d2h(values + (size_t)i * K, vals_p, sizeof(double) * (size_t)K, ws.s));
+    if (vectors) FLGP_TRY(d2h(vectors + (size_t)i * n * K, vecs_p, sizeof(double) * (size_t)n * K, ws.s));
     FLGP_HIP(hipStreamSynchronize(ws.s));
     return FLGP_OK;
   };
@@ -1585,4 +1583,48 @@ extern "C" int flgp_se_spectrum_grid(const double *X_all, int n, int d, const do
   for (int i = 0; i < l; ++i)
     if (rcs[i] != FLGP_OK) { set_error("bandwidth %d (a2=%g): %s", i, a2s[i], msgs[i].c_str()); return rcs[i]; }
   return FLGP_OK;
+}
+
+extern "C" int flgp_se_spectrum_grid(const double *X_all, int n, int d, const double *U, int s, int ucols, int r,
+                                     int K, const double *a2s, int l, const char *gl, int root, double *values,
+                                     double *vectors, double *distances_mean_out, int max_parallel) {
+  const int glc = flgp_parse_gl(gl);
+  if (glc < 0) return glc;
+  FLGP_REQUIRE(a2s && l >= 1 && values && vectors, "se_spectrum_grid: bad arguments");
+  if (K < 0) K = s;
+  FLGP_REQUIRE(K >= 1 && K <= s, "need 1 <= K <= s (K=%d, s=%d)", K, s);
+  Stream st;
+  FLGP_TRY(st.create());
+  Sim S;
+  FLGP_TRY(upload_points(S, st.s, X_all, n, d, U, s, ucols, glc == FLGP_GL_CLUSTER_NORMALIZED));
+  const double *sizes = (ucols == d + 1) ? S.U.as<double>() + (size_t)d * s : nullptr;
+  return se_grid_core(S, st.s, r, K, a2s, l, glc, root, sizes, values, vectors, nullptr, nullptr, distances_mean_out, max_parallel, nullptr);
+}
+
+// The same on device-resident points and anchors (dX n x d column-major ld ldx; dU s x d column-major ld ldu; d_sizes s or
+// NULL): the K values of every bandwidth into d_values (l x K, or NULL) and the vectors into d_vectors (l blocks of n x K
+// column-major, or NULL: not kept -- ten of them are 16 GB at BASELINE configs[2]).  iters_out (or NULL): outer iterations
+// of each bandwidth's eigensolve.  a2s is host memory.  Synchronises.
+extern "C" int flgp_dev_se_spectrum_grid(void *stream, const double *dX, int n, int ldx, int d, const double *dU, int ldu, int s,
+                                         const double *d_sizes, int r, int K, const double *a2s, int l, const char *gl, int root,
+                                         double *d_values, double *d_vectors, double *distances_mean_out, int max_parallel,
+                                         int *iters_out) {
+  hipStream_t st = (hipStream_t)stream;
+  const int glc = flgp_parse_gl(gl);
+  if (glc < 0) return glc;
+  FLGP_REQUIRE(dX && dU && a2s && l >= 1 && n >= 1 && ldx >= n && ldu >= s, "dev_se_spectrum_grid: bad arguments");
+  FLGP_REQUIRE(glc != FLGP_GL_CLUSTER_NORMALIZED || d_sizes, "gl=\"cluster-normalized\" needs the cluster sizes");
+  if (K < 0) K = s;
+  FLGP_REQUIRE(K >= 1 && K <= s, "need 1 <= K <= s (K=%d, s=%d)", K, s);
+  const int dpad = flgp_dev_anchor_dpad(d);
+  FLGP_REQUIRE(dpad > 0, "kernels are built for 1 <= d <= %d (got %d)", FLGP_DMAX, d);
+  Sim S;
+  S.n = n; S.d = d; S.s = s; S.ldx = ldx;
+  S.X.borrow(dX);
+  const int rows = flgp_dev_anchor_rows(s);
+  FLGP_TRY(S.Ut.alloc(sizeof(double) * (size_t)rows * dpad));
+  FLGP_TRY(S.uu.alloc(sizeof(double) * (size_t)rows));
+  FLGP_TRY(flgp_dev_anchor_prep(st, dU, s, ldu, d, S.Ut.as<double>(), S.uu.as<double>()));
+  return se_grid_core(S, st, r, K, a2s, l, glc, root, d_sizes, nullptr, nullptr, d_values, d_vectors, distances_mean_out, max_parallel,
+                      iters_out);
 }
