@@ -1029,6 +1029,19 @@ void bsg_finish(BsG &g) {
     fprintf(stderr, "[flgp eig] block-sparse G: %d non-zeros, %.1f %% of the %dx%d blocks kept for the MFMA product (max %d of %d stages "
             "per tile), %d scattered non-zeros\n", g.h_meta[BSG_M_NNZ], 100.0 * frac, BSG_TM, BSG_SK, g.h_meta[BSG_M_MAXNK], g.nstage,
             g.h_meta[BSG_M_RNNZ]);
+  if (tuning("eig_verbose", 0) > 1) {     // the remainder: entries per row, and per tile
+    std::vector<int> rp(g.s + 1);
+    if (hipMemcpy(rp.data(), g.rptr, sizeof(int) * (g.s + 1), hipMemcpyDeviceToHost) == hipSuccess) {
+      int hist[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+      const int edge[8] = {0, 4, 8, 16, 32, 64, 128, 1 << 30};
+      for (int i = 0; i < g.s; ++i) { const int n = rp[i + 1] - rp[i]; int q = 0; while (n > edge[q]) ++q; ++hist[q]; }
+      fprintf(stderr, "[flgp eig] remainder rows by entries: 0:%d  1-4:%d  5-8:%d  9-16:%d  17-32:%d  33-64:%d  65-128:%d  >128:%d\n",
+              hist[0], hist[1], hist[2], hist[3], hist[4], hist[5], hist[6], hist[7]);
+      fprintf(stderr, "[flgp eig] remainder entries per tile:");
+      for (int t = 0; t < g.ntile; ++t) fprintf(stderr, " %d", rp[std::min(g.s, (t + 1) * BSG_TM)] - rp[t * BSG_TM]);
+      fprintf(stderr, "\n");
+    }
+  }
   if (tuning("eig_verbose", 0) > 1) {     // list lengths of the tiles, longest first
     std::vector<int> nk(g.ntile);
     if (hipMemcpy(nk.data(), g.nk, sizeof(int) * g.ntile, hipMemcpyDeviceToHost) == hipSuccess) {

@@ -1062,6 +1062,7 @@ static JacobiPlan jacobi_plan(int b) {
   p.nloc = 0;
   if (b % 16 == 0 && b >= 32 && tuning("jacobi_scalar", 0) == 0) {
     for (int nloc : {32, 16}) {
+      if (nloc == 32 && tuning("jacobi_nloc", 32) == 16 && b >= 64) continue;      // (experiments: smaller column blocks, more of them)
       if (jac_block_lds(b, nloc) <= 150 * 1024) {
         p.nloc = nloc; p.w = nloc / 2; p.nbc = (b + p.w - 1) / p.w;
         if (p.nbc & 1) ++p.nbc;

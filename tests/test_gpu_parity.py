@@ -578,6 +578,60 @@ def test_blocksparse_product_matches_dense(stages, s, b, density, part_cap):
         L.flgp_set_tuning(b"eig_bs_part_cap", 0)
 
 
+def test_blocksparse_ordering_does_not_depend_on_timing(stages):
+    """Regression for the workspace overrun of round 3 (a229a15): with s % 64 != 0 the chunk tables of the ordering's cluster
+    weights overran their buffer into rows other workgroups of the same launch were reading, so the ORDERING -- kept blocks,
+    scattered entries, hence the solver's iteration count -- depended on who got there first, and it showed only once the
+    set-up's Lanczos steps ran truly concurrently (page-locked result slots).  Here: a Gram matrix of the path with
+    s = 2000 (s % 64 = 16); the set-up's counts (info[2] kept blocks, info[3] scattered entries of flgp_dev_bsg_apply) are the
+    same launch after launch, and the eigensolver -- whose ordering is computed beside the concurrent Lanczos run -- returns
+    the same iteration / product counts and bit-identical eigenvalues on every repeat in BOTH eig_host_slots modes."""
+    import ctypes
+    L = _lib.lib()
+    n, d, s, r, K = 60000, 3, 2000, 5, 100
+    assert s % 64 != 0
+    X, _ = synth.swiss_roll(n, seed=11)
+    U0 = synth.anchors_from_rows(X, np.sort(synth.random_anchor_rows(n, s, seed=11)))
+    dX = cm(X); dU = cm(U0)
+    anchors = stages.anchor_prep(dU)
+    kidx, _ = stages.knn(dX, anchors, r)
+    ei, ev = stages.lae(dX, anchors, kidx)
+    csc = stages.csc(ei, s)
+    stages.row_normalize(ev)
+    c2 = stages.colsum(ei, ev, s); stages.col_scale(ei, ev, c2, None, 1)
+    G = stages.gram(ei, ev, csc)
+    torch.cuda.synchronize()
+    b = 128
+    Xb = torch.randn((b, s), dtype=torch.float64, device="cuda")
+    out = torch.empty((b, s), dtype=torch.float64, device="cuda")
+    wb = L.flgp_dev_bsg_workspace(s, b)
+    work = torch.empty((wb // 8 + 1,), dtype=torch.float64, device="cuda")
+    info = (ctypes.c_int * 6)()
+    st = torch.cuda.current_stream().cuda_stream
+    seen = set(); outs = []
+    for _ in range(6):
+        _lib.check(L.flgp_dev_bsg_apply(st, G.data_ptr(), s, s, Xb.data_ptr(), b, 1.0, 0.0, None, out.data_ptr(), work.data_ptr(), wb,
+                                        ctypes.addressof(info)))
+        torch.cuda.synchronize()
+        seen.add((info[0], info[1], info[2], info[3], info[4]))
+        outs.append(out.cpu().numpy().copy())
+    assert len(seen) == 1 and next(iter(seen))[2] > 0, seen
+    for o in outs[1:]:
+        np.testing.assert_array_equal(o, outs[0])
+    runs = []
+    try:
+        for mode in (1, 0, 1, 0):
+            L.flgp_set_tuning(b"eig_host_slots", mode)
+            for _ in range(3):
+                eig, V, inf = stages.eig_topk(G, K)
+                runs.append((mode, inf["outer_iterations"], inf["g_products"], eig.cpu().numpy().copy()))
+    finally:
+        L.flgp_set_tuning(b"eig_host_slots", 1)
+    assert len({(r_[1], r_[2]) for r_ in runs}) == 1, [(r_[0], r_[1], r_[2]) for r_ in runs]
+    for r_ in runs[1:]:
+        np.testing.assert_array_equal(r_[3], runs[0][3])
+
+
 # ------------------------------------------------------------------------------ spectrum + heat kernel
 @pytest.mark.parametrize("n,d,s,r,K,root,gl", [
     (1500, 3, 120, 4, 20, True, "cluster-normalized"),
