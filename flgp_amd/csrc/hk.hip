@@ -202,10 +202,31 @@ __global__ void hk_scale_pad_kernel(const double *__restrict__ values, int K, in
   Vw[e] = v;
 }
 
+// per-device figures (the first caller's CU count was used for every device, and a device with less LDS than
+// the panel needs made the launch fail instead of taking the tiled GEMM that is still in the dispatcher)
+static void hk_device_figures(int *n_cu, int *lds_max) {
+  static int cu_cache[64], lds_cache[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+  if (!cu_cache[dev]) {
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+    cu_cache[dev] = v;
+    v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess || v <= 0) v = 65536;
+    lds_cache[dev] = v;
+  }
+  if (n_cu) *n_cu = cu_cache[dev];
+  if (lds_max) *lds_max = lds_cache[dev];
+}
+
 bool hk_panel_applicable(int n0, int n1, int K, long ldh) {
   const int nst = (K + 15) / 16;
+  int lds_max = 0;
+  hk_device_figures(nullptr, &lds_max);
   return tuning("hk_panel", 1) && nst <= HK_MAX_NST && n1 >= tuning("hk_panel_min_n1", 64) &&
-         n0 >= tuning("hk_panel_min_n0", 2048) && ldh <= 150000000L;   // (a lane's store offset (3 ldh + 15) * 8 stays in 32 bits)
+         n0 >= tuning("hk_panel_min_n0", 2048) && ldh <= 150000000L &&   // (a lane's store offset (3 ldh + 15) * 8 stays in 32 bits)
+         (size_t)lds_max >= sizeof(double) * (size_t)nst * 16 * HP;      // (the panel in LDS)
 }
 
 // doubles of the small operand's buffer: the larger of the two layouts (hk.hip: rows padded to 16; hk2.hip: to tile pairs)
@@ -228,13 +249,8 @@ int hk_panel_launch(hipStream_t st, const double *d_values, int K, double t, con
   g.K = K; g.nst = nst;
   g.H = dH; g.ldh = ldh;
   g.nblocks = ceil_div(n0, HP);
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0, v = 0;
-    (void)hipGetDevice(&dev);
-    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-    n_cu = v;
-  }
+  int n_cu = 256;
+  hk_device_figures(&n_cu, nullptr);
   int grid = n_cu * tuning("hk_panel_wg_per_cu", 1);
   if (grid > g.nblocks) grid = g.nblocks;
   const size_t lds = sizeof(double) * (size_t)nst * 16 * HP;

@@ -294,7 +294,12 @@ extern "C" int flgp_kmeans_minibatch(const double *X, int n, int d, int s, int b
         std::swap(perm[p], perm[j]);
       }
       FLGP_HIP(hipMemcpyAsync(dbatch.p, perm.data(), sizeof(int) * (size_t)B, hipMemcpyHostToDevice, st));
+      // the stop flag of the iterations so far comes back with the same synchronisation (looked at only every
+      // eighth iteration, up to seven idle iterations -- k-NN pass, CSC build, upload -- were enqueued behind the latch)
+      int hs[4] = {0, 0, 0, 0};
+      if (it > 0) FLGP_HIP(hipMemcpyAsync(hs, dstate.p, sizeof(hs), hipMemcpyDeviceToHost, st));
       FLGP_HIP(hipStreamSynchronize(st));    // (the next iteration shuffles perm again)
+      if (hs[2]) break;
       const int *state = dstate.as<int>();
       hipLaunchKernelGGL(mb_gather_kernel, dim3(ceil_div((long)B * d, 256)), dim3(256), 0, st, dX.as<double>(), n, d, dbatch.as<int>(), B,
                          Xb.as<double>(), state);
@@ -308,12 +313,6 @@ extern "C" int flgp_kmeans_minibatch(const double *X, int n, int d, int s, int b
                          cnt[it & 1].as<double>(), cnt[(it + 1) & 1].as<double>(), state);
       hipLaunchKernelGGL(mb_latch_kernel, dim3(1), dim3(64), 0, st, dstate.as<int>());
       FLGP_TRY(check_launch("mini-batch iteration"));
-      if ((it & 7) == 7) {                   // look at the stop flag now and then: no point in enqueuing 90 idle iterations
-        int hs[4];
-        FLGP_HIP(hipMemcpyAsync(hs, dstate.p, sizeof(hs), hipMemcpyDeviceToHost, st));
-        FLGP_HIP(hipStreamSynchronize(st));
-        if (hs[2]) break;
-      }
     }
     // ---- evaluation over all points: 1-NN labels, within-SS, sizes
     FLGP_TRY(flgp_dev_anchor_prep(st, C, s, s, d, Ut.as<double>(), uu.as<double>()));
