@@ -429,6 +429,12 @@ int flgp_oracle_u_recover(const int *ell_idx, const double *ell_val, int n, int 
  * HK_from_spectrum_cpp, src/Spectrum.cpp:83-94:
  *   H(a,b) = sum_k V(idx0[a],k) exp(-t (1 - values_k)) V(idx1[b],k)
  * vectors: n x ldk... column-major with leading dimension n; H: n0 x n1.
+ * ASSOCIATION (the one place the restatement departs from the source line): the reference evaluates
+ * (V0 * diag(w)) * V1^T (src/Spectrum.cpp:90: the weights multiply the LEFT factor, then Eigen's GEMM, whose summation
+ * order is unspecified); here the weights are folded into the RIGHT factor, V1(b,k) w_k, and the sum over k is an
+ * ascending FMA chain -- the form the HIP kernel computes (the small operand carries the weights, the n x K operand is
+ * read as it is).  v0 (w v1) and (v0 w) v1 differ by one rounding per term: within the 1e-8 tolerance of the path by
+ * eight orders of magnitude, and not a difference any agreement with the reference binary could resolve.
  * ------------------------------------------------------------------------- */
 int flgp_oracle_hk(const double *values, const double *vectors, int n, int K, double t,
                    const int *idx0, int n0, const int *idx1, int n1, double *H) {

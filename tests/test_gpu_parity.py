@@ -1142,6 +1142,13 @@ def test_full_size_properties(oracle, stages):
     w_o = w_o[::-1]; V_o = V_o[:, ::-1]
     vals = res.values.cpu().numpy()
     np.testing.assert_allclose(vals ** 2, w_o, rtol=EIG_RTOL, atol=0)                  # root=True: values = sigma
+    # ... and against the REFERENCE's route at this size (src/TruncatedSVD.cpp:23-30: RSpectra::svds on A itself, restated
+    # with ARPACK's implicitly restarted Lanczos, tol 1e-10, ncv = 2K + 1): the singular values of the 1e6 x 5000 matrix
+    from scipy.sparse.linalg import svds as _svds
+    A_o = oracle.ell_to_csr(ei_o, av_o, s).tocsc()
+    sv = _svds(A_o, k=K, ncv=2 * K + 1, tol=1e-10, which="LM", v0=np.random.default_rng(0).standard_normal(s), maxiter=1000 * s,
+               return_singular_vectors=False)
+    np.testing.assert_allclose(vals, np.sort(sv)[::-1], rtol=1e-9, atol=0)
     pick = np.concatenate([np.arange(m), np.arange(123456, 123456 + 2048), np.arange(n - 1024, n)])
     Uo = oracle.u_recover(ei_o[pick], av_o[pick], s, np.asfortranarray(V_o), np.sqrt(w_o))
     vec_o = np.asfortranarray(Uo * (np.sqrt(float(n)) / np.sqrt(float(pick.size))))    # (the oracle scales by sqrt(rows given))
