@@ -135,6 +135,11 @@ struct Sim {
   const flgp_comm *comm = nullptr;
   long n_global = 0;
   const double *sizes = nullptr;
+  // the CSC view depends on the PATTERN alone, the Laplacian passes only touch the values: the view is built on a second
+  // stream beside them (round 4) and joined before the Gram kernel, its first reader
+  hipEvent_t csc_ev = nullptr;
+  bool csc_pending = false, want_csc = false;
+  ~Sim() { if (csc_ev) { (void)hipEventSynchronize(csc_ev); (void)hipEventDestroy(csc_ev); } }
 };
 
 int upload_points(Sim &S, hipStream_t st, const double *X, int n, int d, const double *U, int s, int ucols,
@@ -197,6 +202,33 @@ int build_csc(Sim &S, hipStream_t st) {
   return FLGP_OK;
 }
 
+// one second stream per host thread and device for work that may run beside the caller's stream (never destroyed)
+static hipStream_t side_stream() {
+  thread_local hipStream_t side[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  if (!side[dev] && hipStreamCreateWithFlags(&side[dev], hipStreamNonBlocking) != hipSuccess) side[dev] = nullptr;
+  return side[dev];
+}
+
+// the CSC view on the second stream, ordered behind what `st` holds now; join_csc() makes `st` wait for it
+int build_csc_async(Sim &S, hipStream_t st) {
+  if (S.have_csc) return FLGP_OK;
+  hipStream_t sd = tuning("csc_async", 1) ? side_stream() : nullptr;
+  if (!sd) return build_csc(S, st);
+  if (!S.csc_ev) FLGP_HIP(hipEventCreateWithFlags(&S.csc_ev, hipEventDisableTiming));
+  FLGP_HIP(hipEventRecord(S.csc_ev, st));
+  FLGP_HIP(hipStreamWaitEvent(sd, S.csc_ev, 0));
+  FLGP_TRY(build_csc(S, sd));
+  FLGP_HIP(hipEventRecord(S.csc_ev, sd));
+  S.csc_pending = true;
+  return FLGP_OK;
+}
+int join_csc(Sim &S, hipStream_t st) {
+  if (S.csc_pending) { FLGP_HIP(hipStreamWaitEvent(st, S.csc_ev, 0)); S.csc_pending = false; }
+  return FLGP_OK;
+}
+
 // graphLaplacian_cpp on the device ELL (reference src/Utils.cpp:195-212)
 int laplacian(Sim &S, hipStream_t st, int gl, const double *d_num_class) {
   if (gl != FLGP_GL_RW) {
@@ -219,6 +251,7 @@ int cross_similarity(Sim &S, hipStream_t st, int r, int kernel_se, int gl, doubl
     FLGP_TRY(flgp_dev_lae(st, S.X.as<double>(), S.n, S.ldx ? S.ldx : S.n, S.d, S.Ut.as<double>(), S.s, r, S.knn_idx.as<int>(), S.n,
                           S.ell_idx.as<int>(), S.ell_val.as<double>()));
   if (gl < 0) return FLGP_OK;  // LAE_cpp alone: no graph-Laplacian normalisation
+  if (S.want_csc) FLGP_TRY(build_csc_async(S, st));     // (callers that go on to the spectrum: beside the Laplacian passes)
   const double *sizes = S.sizes ? S.sizes : ((ucols == S.d + 1) ? S.U.as<double>() + (size_t)S.d * S.s : nullptr);  // U.col(d)
   return laplacian(S, st, gl, sizes);
 }
@@ -243,13 +276,14 @@ int spectrum(Sim &S, hipStream_t st, int K, int root, Spectrum &P, int *info) {
   if (K < 0) K = S.s;   // reference: K < 0 -> s (src/Spectrum.cpp:31-33,69-71; src/TruncatedSVD.cpp:11-13)
   FLGP_REQUIRE(K >= 1 && K <= S.s, "need 1 <= K <= s (K=%d, s=%d)", K, S.s);
   P.K = K;
-  FLGP_TRY(build_csc(S, st));
+  FLGP_TRY(build_csc_async(S, st));     // (no-op when cross_similarity has started it already)
   // A = Z diag(1/sqrt(|colsum|+1e-9))  (:149-150)
   FLGP_TRY(colsum_of(S, st, S.ell_idx.as<int>(), S.ell_val.as<double>()));
   FLGP_TRY(flgp_comm_all_reduce_sum(S.comm, S.colsum.as<double>(), (size_t)S.s, st));              // exchange 2b
   FLGP_TRY(flgp_dev_col_scale(st, S.ell_idx.as<int>(), S.ell_val.as<double>(), S.n, S.r, S.colsum.as<double>(), nullptr, 1));
   // Gram + top-K eigenpairs (replaces RSpectra::svds / BDCSVD, src/TruncatedSVD.cpp:17-30)
   FLGP_TRY(P.G.alloc(sizeof(double) * (size_t)S.s * S.s));
+  FLGP_TRY(join_csc(S, st));
   FLGP_TRY(flgp_dev_gram(st, S.ell_idx.as<int>(), S.ell_val.as<double>(), S.n, S.s, S.r, S.colptr.as<int>(),
                          S.pos.as<int>(), P.G.as<double>(), S.s));
   if (flgp_comm_world(S.comm) > 1) {
@@ -716,6 +750,7 @@ extern "C" int flgp_heat_kernel_spectrum_resident(const double *X_all, int n, in
   FLGP_TRY(st.create());
   Sim S;
   FLGP_TRY(upload_points(S, st.s, X_all, n, d, U, s, ucols, glc == FLGP_GL_CLUSTER_NORMALIZED));
+  S.want_csc = true;
   FLGP_TRY(cross_similarity(S, st.s, r, se, glc, epsilon, ucols));
   Spectrum P;
   FLGP_TRY(spectrum(S, st.s, K, root, P, nullptr));
@@ -1164,6 +1199,7 @@ extern "C" int flgp_heat_kernel_spectrum(const double *X_all, int n, int d, cons
   FLGP_TRY(st.create());
   Sim S;
   FLGP_TRY(upload_points(S, st.s, X_all, n, d, U, s, ucols, glc == FLGP_GL_CLUSTER_NORMALIZED));
+  S.want_csc = true;
   FLGP_TRY(cross_similarity(S, st.s, r, se, glc, epsilon, ucols));
   Spectrum P;
   FLGP_TRY(spectrum(S, st.s, K, root, P, nullptr));
@@ -1189,6 +1225,7 @@ extern "C" int flgp_heat_kernel_covariance(const double *X_all, int n, int m, in
   const double t0 = now();
   FLGP_TRY(upload_points(S, st.s, X_all, n, d, U, s, ucols, glc == FLGP_GL_CLUSTER_NORMALIZED));
   const double t1 = now();
+  S.want_csc = true;
   FLGP_TRY(cross_similarity(S, st.s, r, se, glc, epsilon, ucols));
   Spectrum P;
   FLGP_TRY(spectrum(S, st.s, K, root, P, nullptr));
@@ -1316,6 +1353,7 @@ extern "C" int flgp_dev_heat_kernel_covariance_sharded(void *stream, const flgp_
   FLGP_TRY(S.Ut.alloc(sizeof(double) * (size_t)rows * dpad));
   FLGP_TRY(S.uu.alloc(sizeof(double) * (size_t)rows));
   FLGP_TRY(flgp_dev_anchor_prep(st, dU, s, ldu, d, S.Ut.as<double>(), S.uu.as<double>()));
+  S.want_csc = true;
   FLGP_TRY(cross_similarity(S, st, r, se, glc, epsilon, d));
   Spectrum P;
   FLGP_TRY(spectrum(S, st, K, root, P, info));

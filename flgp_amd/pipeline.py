@@ -192,6 +192,11 @@ class HipStages:
     def timer(self):
         return _CudaTimer(self.device)
 
+    def side_stream(self):
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream(device=self.device)
+        return self._side
+
 
 class _CudaTimer:
     """HIP-event timer on the stream the kernels are launched on (torch's current stream)."""
@@ -326,9 +331,13 @@ class HeatKernelPath:
         else:
             ell_idx, ell_val = S.se_weights(knn_idx, knn_dist, cfg.epsilon)
         tm.mark("similarity")
-        # k5: graph Laplacian (reference src/Utils.cpp:195-212)
-        csc = S.csc(ell_idx, s)
-        tm.mark("csc")
+        # k5: graph Laplacian (reference src/Utils.cpp:195-212).  The CSC view depends on the pattern alone and the scalings
+        # only touch the values: the view is built on a second stream beside them and joined before the Gram kernel.
+        main = torch.cuda.current_stream(S.device)
+        side = S.side_stream()
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            csc = S.csc(ell_idx, s)
         if gl != 0:
             c = self._all_reduce(S.colsum(ell_idx, ell_val, s))                # exchange 2a
             S.col_scale(ell_idx, ell_val, c, num_class if gl == 2 else None, 0)
@@ -337,6 +346,10 @@ class HeatKernelPath:
         c2 = self._all_reduce(S.colsum(ell_idx, ell_val, s))                   # exchange 2b
         S.col_scale(ell_idx, ell_val, c2, None, 1)
         tm.mark("laplacian")
+        main.wait_stream(side)
+        for tns in (csc["colptr"], csc["pos"]):
+            tns.record_stream(main)
+        tm.mark("csc")                                                        # (what of the CSC build the scalings did not cover)
         # k6: Gram, replicated top-K eigensolve
         G = S.gram(ell_idx, ell_val, csc)
         if self.dist and self.world > 1:                                      # exchange 3: the upper triangle only
