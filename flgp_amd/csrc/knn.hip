@@ -19,6 +19,7 @@
 // point from turning into a divergent branch on every candidate: a wave with 64 lanes would
 // otherwise take the insertion path for a third of all candidates at s = 5000, r = 10.
 #include "common.h"
+#include "knn_top.h"
 
 namespace flgp {
 
@@ -83,51 +84,6 @@ __global__ void anchor_prep_kernel(const double *__restrict__ U, int s, int s_pa
   c1[j] = usable ? (float)(-0.5 * acc * (1.0 + (double)KNN_SCREEN_MU)) : -KNN_SCREEN_BIG;
   c2[j] = usable ? (float)(-0.5 * acc * (1.0 - (double)KNN_SCREEN_MU)) : (j < s ? KNN_SCREEN_BIG : -KNN_SCREEN_BIG);
 }
-
-// Sorted list of the RCAP smallest (value, index) pairs, ascending.  The first RCAP - r slots
-// are pinned by -inf sentinels so that the r-th best real candidate is always bd[RCAP-1]
-// (a compile-time register), whatever the run-time r.
-template <int RCAP>
-struct TopList {
-  double bd[RCAP];
-  int bi[RCAP];
-  __device__ __forceinline__ void init(int r) {
-#pragma unroll
-    for (int k = 0; k < RCAP; ++k) {
-      bd[k] = (k < RCAP - r) ? -__builtin_inf() : __builtin_inf();
-      bi[k] = (k < RCAP - r) ? -1 : 0x7fffffff;
-    }
-  }
-  __device__ __forceinline__ double thr() const { return bd[RCAP - 1]; }
-  // strict '<': an equal distance never moves ahead of an earlier (lower) index
-  __device__ __forceinline__ void insert(double D, int j) {
-#pragma unroll
-    for (int k = RCAP - 1; k >= 1; --k) {
-      const bool c1 = D < bd[k - 1];
-      const bool c0 = D < bd[k];
-      bd[k] = c1 ? bd[k - 1] : (c0 ? D : bd[k]);
-      bi[k] = c1 ? bi[k - 1] : (c0 ? j : bi[k]);
-    }
-    const bool c0 = D < bd[0];
-    bd[0] = c0 ? D : bd[0];
-    bi[0] = c0 ? j : bi[0];
-  }
-  // order by (distance, index): the list a scan in ascending index with the strict '<' above ends with, whatever the
-  // order the candidates come in.  D must be below +inf (the scan never takes such an anchor).
-  __device__ __forceinline__ bool before(double D, int j, int k) const { return D < bd[k] || (D == bd[k] && j < bi[k]); }
-  __device__ __forceinline__ void insert_lex(double D, int j) {
-#pragma unroll
-    for (int k = RCAP - 1; k >= 1; --k) {
-      const bool c1 = before(D, j, k - 1);
-      const bool c0 = before(D, j, k);
-      bd[k] = c1 ? bd[k - 1] : (c0 ? D : bd[k]);
-      bi[k] = c1 ? bi[k - 1] : (c0 ? j : bi[k]);
-    }
-    const bool c0 = before(D, j, 0);
-    bd[0] = c0 ? D : bd[0];
-    bi[0] = c0 ? j : bi[0];
-  }
-};
 
 template <int DP>
 constexpr int knn_tile_anchors() { return DP <= 16 ? 128 : (DP <= 32 ? 64 : 32); }
@@ -896,6 +852,11 @@ static int launch_knn_screen(hipStream_t st, const double *dX, int n, int ldx, i
 
 }  // namespace flgp
 
+namespace flgp {
+int knn_wide(hipStream_t st, const double *dX, int n, int ldx, int d, const double *dUt, int dpad, const double *duu, int s,
+             int r, int *d_idx, double *d_dist, int ldo);   // knn_wide.hip
+}
+
 using namespace flgp;
 
 extern "C" int flgp_dev_anchor_dpad(int d) {
@@ -904,6 +865,7 @@ extern "C" int flgp_dev_anchor_dpad(int d) {
   if (d <= 16) return 16;
   if (d <= 32) return 32;
   if (d <= 64) return 64;
+  if (d <= FLGP_DMAX) return (d + 7) / 8 * 8;   // rows of whole 64-byte lines: the GEMM route of knn_wide.hip and the LDS-free LAE
   return -1;
 }
 
@@ -943,6 +905,7 @@ extern "C" int flgp_dev_knn(void *stream, const double *dX, int n, int ldx, int 
   FLGP_REQUIRE(r <= FLGP_RMAX, "KNN: r=%d exceeds the built maximum %d", r, FLGP_RMAX);
   FLGP_REQUIRE(ldx >= n && ldo >= n, "KNN: leading dimensions must be >= n");
   if (n == 0) return FLGP_OK;
+  if (dpad > 64) return knn_wide(st, dX, n, ldx, d, dUt, dpad, duu, s, r, d_idx, d_dist, ldo);
   const int rcap = r <= 4 ? 4 : (r <= 8 ? 8 : (r <= 16 ? 16 : 32));
   const int variant = tuning("knn_variant", 0);
   if (r == 1 && tuning("knn_nn1", 1)) {   // the 1-NN of Lloyd's assignment step and of the cluster counts

@@ -94,13 +94,12 @@ __global__ void mb_pp_pick_kernel(const double *__restrict__ X, int ldx, int d, 
 // first centre: row sub[pick]
 __global__ void mb_pp_first_kernel(const double *__restrict__ X, int ldx, int d, const int *__restrict__ sub, int pick,
                                    double *__restrict__ C, int s, double *__restrict__ cnew, int *__restrict__ picked) {
-  const int k = threadIdx.x;
-  if (k < d) {
+  for (int k = threadIdx.x; k < d; k += blockDim.x) {
     const double v = X[(size_t)k * ldx + sub[pick]];
     C[(size_t)k * s] = v;
     cnew[k] = v;
   }
-  if (k == 0) picked[0] = pick;
+  if (threadIdx.x == 0) picked[0] = pick;
 }
 
 // Xb(p, k) = X(batch[p], k): the batch as a B x d column-major block

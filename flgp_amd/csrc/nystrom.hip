@@ -81,6 +81,22 @@ __global__ __launch_bounds__(256) void nys_exp_rows_kernel(double *__restrict__ 
   part2[(size_t)blockIdx.y * nb + x] = a2;
 }
 
+// the same on the dot products of the anchors with themselves: Z(x, j) = D(x, j), row sums in part1 (MODE 0 of nys_sim_kernel)
+__global__ __launch_bounds__(256) void nys_dist_rows_kernel(double *__restrict__ Z, int nb, int s, const double *__restrict__ xx,
+                                                            const double *__restrict__ uu, double *__restrict__ part1) {
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  if (x >= nb) return;
+  const double xn = xx[x];
+  const int j0 = blockIdx.y * 64, j1 = (j0 + 64 < s) ? j0 + 64 : s;
+  double a1 = 0.0;
+  for (int j = j0; j < j1; ++j) {
+    const double D = __builtin_fma(-2.0, Z[(size_t)j * nb + x], xn) + uu[j];
+    Z[(size_t)j * nb + x] = D;
+    a1 += D;
+  }
+  part1[(size_t)blockIdx.y * nb + x] = a1;
+}
+
 // r1[x] = sum over chunks (ascending) of part1[chunk][x] (+ add1); same for r2
 __global__ void nys_reduce_kernel(const double *__restrict__ part1, const double *__restrict__ part2, int nchunk, int nb,
                                   double add1, double *__restrict__ r1, double *__restrict__ r2) {
@@ -169,6 +185,7 @@ static int launch_sim(hipStream_t st, int dpad, const double *X, int nb, int ldx
 #define NYS_CASE(DPv) if (dpad == DPv) hipLaunchKernelGGL((nys_sim_kernel<DPv, MODE>), grid, dim3(256), 0, st, X, nb, ldx, d, Ut, uu, s, inv_c, w, out, ldo, p1, p2);
   NYS_CASE(4) NYS_CASE(8) NYS_CASE(16) NYS_CASE(32) NYS_CASE(64)
 #undef NYS_CASE
+  FLGP_REQUIRE(dpad <= 64, "nystrom: no register kernel for dpad = %d (the GEMM route serves d > 64)", dpad);
   return check_launch("nys_sim_kernel");
 }
 
@@ -219,8 +236,18 @@ extern "C" int flgp_dev_nystrom_eigenpair(void *stream, const double *dX, int n,
   FLGP_TRY(nrm.alloc(sizeof(double) * (size_t)K));
   FLGP_TRY(flgp_dev_anchor_prep(st, dU, s, ldu, d, Ut.as<double>(), uu.as<double>()));
   // ---- D_UU and its mean (src/Fit.cpp:244,248)
-  FLGP_TRY((launch_sim<0>(st, dpad, dU, s, ldu, d, Ut.as<double>(), uu.as<double>(), s, 0.0, nullptr, W.as<double>(), s,
-                          p1.as<double>(), nullptr)));
+  if (dpad > 64) {   // no register kernel beyond d = 64: dot products by the GEMM (one chain per element, the same bits)
+    hipLaunchKernelGGL(nys_sqnorm_kernel, dim3(ceil_div(s, 256)), dim3(256), 0, st, dU, s, ldu, d, fac.as<double>());
+    FLGP_TRY(check_launch("nys_sqnorm_kernel"));
+    FLGP_TRY(gemm_launch(st, s, s, d, 1.0, dU, 1, ldu, dU, ldu, 1, 0.0, nullptr, 0, 0, W.as<double>(), 1, s, nullptr, 0, 0.0,
+                         nullptr));
+    hipLaunchKernelGGL(nys_dist_rows_kernel, dim3(ceil_div(s, 256), nchunk), dim3(256), 0, st, W.as<double>(), s, s,
+                       fac.as<double>(), uu.as<double>(), p1.as<double>());
+    FLGP_TRY(check_launch("nys_dist_rows_kernel"));
+  } else {
+    FLGP_TRY((launch_sim<0>(st, dpad, dU, s, ldu, d, Ut.as<double>(), uu.as<double>(), s, 0.0, nullptr, W.as<double>(), s,
+                            p1.as<double>(), nullptr)));
+  }
   hipLaunchKernelGGL(nys_reduce_kernel, dim3(ceil_div(s, 256)), dim3(256), 0, st, p1.as<double>(), nullptr, nchunk, s, 0.0,
                      rsx.as<double>(), nullptr);
   FLGP_TRY(check_launch("nys_reduce_kernel"));

@@ -333,10 +333,13 @@ class HeatKernelPath:
         tm.mark("similarity")
         # k5: graph Laplacian (reference src/Utils.cpp:195-212).  The CSC view depends on the pattern alone and the scalings
         # only touch the values: the view is built on a second stream beside them and joined before the Gram kernel.
-        main = torch.cuda.current_stream(S.device)
-        side = S.side_stream()
-        side.wait_stream(main)
-        with torch.cuda.stream(side):
+        side = S.side_stream() if hasattr(S, "side_stream") else None       # (a stage set without streams builds it in line)
+        if side is not None:
+            main = torch.cuda.current_stream(S.device)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                csc = S.csc(ell_idx, s)
+        else:
             csc = S.csc(ell_idx, s)
         if gl != 0:
             c = self._all_reduce(S.colsum(ell_idx, ell_val, s))                # exchange 2a
@@ -346,9 +349,10 @@ class HeatKernelPath:
         c2 = self._all_reduce(S.colsum(ell_idx, ell_val, s))                   # exchange 2b
         S.col_scale(ell_idx, ell_val, c2, None, 1)
         tm.mark("laplacian")
-        main.wait_stream(side)
-        for tns in (csc["colptr"], csc["pos"]):
-            tns.record_stream(main)
+        if side is not None:
+            main.wait_stream(side)
+            for tns in (csc["colptr"], csc["pos"]):
+                tns.record_stream(main)
         tm.mark("csc")                                                        # (what of the CSC build the scalings did not cover)
         # k6: Gram, replicated top-K eigensolve
         G = S.gram(ell_idx, ell_val, csc)

@@ -43,7 +43,9 @@ def to_np_cm(t):
 # ------------------------------------------------------------------------------ k-NN (k1+k2)
 @pytest.mark.parametrize("n,d,s,r", [
     (1000, 2, 150, 3), (777, 16, 333, 10), (513, 3, 128, 1), (300, 64, 140, 5), (200, 17, 50, 20),
-    (100, 1, 10, 10), (5, 2, 2, 2), (4097, 16, 1025, 16), (256, 8, 200, 32)])
+    (100, 1, 10, 10), (5, 2, 2, 2), (4097, 16, 1025, 16), (256, 8, 200, 32),
+    # d > 64: dot products by the GEMM, one lane per point selects (csrc/knn_wide.hip)
+    (600, 65, 130, 5), (500, 100, 257, 10), (300, 784, 200, 3), (1000, 130, 300, 1), (257, 200, 64, 32), (3, 70, 2, 2)])
 def test_knn_bit_exact(oracle, n, d, s, r):
     X, U0, _ = make_case(n, d, s, r, seed=1000 + n + d, with_sizes=False)
     res = api.KNN_cpp(X, U0, r, output=True)
@@ -182,14 +184,31 @@ def test_knn_ties_and_duplicates(oracle):
         np.testing.assert_array_equal(api.KNN_cpp(X, U, r)["ind_knn"], oracle.knn(X, U, r))
 
 
+def test_knn_wide_in_several_row_blocks(oracle):
+    """d > 64 walks the points in row blocks (sized for a 1 GB block of dot products): forced small here, with a ragged
+    last block."""
+    n, d, s, r = 1500, 96, 333, 7
+    X, U0, _ = make_case(n, d, s, r, seed=77, with_sizes=False)
+    L = _lib.lib()
+    L.flgp_set_tuning(b"knn_wide_block", 512)
+    try:
+        res = api.KNN_cpp(X, U0, r, output=True)
+    finally:
+        L.flgp_set_tuning(b"knn_wide_block", 0)
+    oi, od = oracle.knn(X, U0, r, output=True)
+    np.testing.assert_array_equal(res["ind_knn"], oi)
+    order = np.argsort(oi, axis=1, kind="stable")
+    np.testing.assert_array_equal(res["distances_sp"].data.reshape(n, r), np.take_along_axis(od, order, axis=1))
+
+
 def test_knn_errors():
     X = np.zeros((4, 2)); U = np.zeros((3, 2))
     with pytest.raises(api.FlgpError) as e:
         api.KNN_cpp(X, U, 4)          # r > s: undefined behaviour in the reference, an error here
     assert e.value.code == -1
     with pytest.raises(api.FlgpError) as e:
-        api.KNN_cpp(np.zeros((4, 65)), np.zeros((3, 65)), 2)
-    assert e.value.code == -1 and "<= 64" in e.value.message
+        api.KNN_cpp(np.zeros((4, 16385)), np.zeros((3, 16385)), 2)
+    assert e.value.code == -1 and "<= 16384" in e.value.message
 
 
 def test_bad_inputs_are_refused_not_faulted(oracle):
@@ -249,7 +268,9 @@ def test_v_to_z(oracle):
 @pytest.mark.parametrize("r,d", [(1, 2), (2, 2), (3, 2), (5, 3), (8, 16), (10, 16), (12, 4), (16, 3), (20, 2), (10, 64),
                                  (10, 12), (10, 17), (10, 32), (10, 40), (7, 16), (9, 33), (13, 8), (16, 16), (14, 30),
                                  # few anchors over several lanes per point: the shapes a missing fence broke (sweep_lae.py)
-                                 (2, 40), (3, 17), (4, 40), (5, 32), (5, 64), (6, 24), (8, 48), (2, 64), (11, 20), (16, 32)])
+                                 (2, 40), (3, 17), (4, 40), (5, 32), (5, 64), (6, 24), (8, 48), (2, 64), (11, 20), (16, 32),
+                                 # d > 64: the kernel that reads the anchors from the panel in memory
+                                 (3, 100), (10, 65), (5, 784), (12, 130), (20, 72)])
 def test_lae_bit_exact(oracle, r, d):
     n, s = 500, 64
     X, U0, _ = make_case(n, d, s, r, seed=31 * r + d, with_sizes=False)
@@ -637,6 +658,7 @@ def test_blocksparse_ordering_does_not_depend_on_timing(stages):
     (1500, 3, 120, 4, 20, True, "cluster-normalized"),
     (1500, 3, 120, 4, -1, False, "rw"),                 # K == s: the dense (BDCSVD) branch
     (4000, 16, 700, 10, 50, True, "normalized"),        # the block eigensolver branch
+    (2500, 100, 300, 5, 40, True, "cluster-normalized"),   # d > 64 (an image-like input)
 ])
 def test_spectrum_and_heat_kernel(oracle, n, d, s, r, K, root, gl):
     X, U0, U = make_case(n, d, s, r, seed=n + s + r)
@@ -860,7 +882,8 @@ def test_posterior_variance_many_new_rows(oracle):
 
 
 @pytest.mark.parametrize("n,d,s,a2,K,seed", [(3000, 3, 300, 1.0, 30, 0), (5000, 7, 500, 0.5, 60, 1),
-                                              (2000, 16, 257, 10.0, 20, 2), (700, 2, 64, 0.1, 64 // 4, 3)])
+                                              (2000, 16, 257, 10.0, 20, 2), (700, 2, 64, 0.1, 64 // 4, 3),
+                                              (1500, 100, 200, 2.0, 20, 4)])
 def test_nystrom_eigenpair(oracle, n, d, s, a2, K, seed):
     """the Nystrom-extension spectrum of fit_nystrom_* (reference src/Fit.cpp:244-289) against the numpy
     restatement.  fp64 tolerance, not bit-exact: the reference's distances come from an Eigen GEMM and its eigenpairs
@@ -933,7 +956,8 @@ def test_nystrom_row_shards_bit_identical(oracle):
 
 
 @pytest.mark.parametrize("n,d,s,iter_max,seed", [(1200, 2, 4, 100, 0), (5000, 3, 60, 100, 1), (3000, 16, 200, 100, 2),
-                                                  (4000, 7, 129, 3, 3), (900, 33, 50, 100, 4), (64, 1, 64, 5, 5)])
+                                                  (4000, 7, 129, 3, 3), (900, 33, 50, 100, 4), (64, 1, 64, 5, 5),
+                                                  (1500, 90, 40, 100, 6)])
 def test_kmeans_lloyd_bit_exact(oracle, n, d, s, iter_max, seed):
     """Lloyd k-means on the device against its restatement -- labels come from the bit-exact k-NN kernel and
     the centre sums are taken in row order, so centres, sizes and the number of rounds all agree exactly."""
@@ -1571,7 +1595,8 @@ def test_r_default_k_minus_one_past_4096_anchors(oracle):
     assert np.abs(VtV - np.eye(s)).max() < 1e-7
 
 
-@pytest.mark.parametrize("n,d,s,num_init,seed", [(3000, 3, 40, 1, 1), (5000, 16, 64, 2, 7), (2100, 2, 300, 1, 3)])
+@pytest.mark.parametrize("n,d,s,num_init,seed", [(3000, 3, 40, 1, 1), (5000, 16, 64, 2, 7), (2100, 2, 300, 1, 3),
+                                                  (2000, 80, 50, 1, 5)])
 def test_kmeans_minibatch(oracle, n, d, s, num_init, seed):
     """SURVEY 8f-4, second half: the mini-batch k-means of subsample_cpp's "minibatchkmeans" branch (src/Utils.cpp:49-62:
     ClusterR::MiniBatchKmeans with batch_size = 10 s, kmeans++ on 20 s of the rows, at most 100 iterations, early stop 10)
