@@ -113,7 +113,21 @@ inline int check_launch(const char *what) {
 int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double *A, long a_is, long a_ks,
                 const double *B, long b_ks, long b_js, double beta, const double *E, long e_is, long e_js,
                 double *C, long c_is, long c_js, double *work, size_t work_elems, double gamma,
-                const double *E2, int *tickets = nullptr);
+                const double *E2, int *tickets = nullptr, struct GemmFusedReduce *fused = nullptr);
+// Optional extra work for the split-K reduction kernel of a SQUARE product S (M == N, alpha = 1, no E / E2), so that the
+// eigensolver's small matrices need no kernels of their own behind the product:
+//   mode bit 0: S <- D S D with D = diag(1 / sqrt(S_jj)) (0 where S_jj <= 0), D stored in dinv;
+//        bit 1: only the strictly upper triangle (row < column) of S is kept, the rest zero;
+//        bit 2: |S - I|_F^2 (after bits 0 / 1) as GEMM_DIST_PARTS partial sums in a fixed order into dist[] (may be host memory).
+// `scratch` holds one double per 16 x 16 tile of S, `counter` one int that is zero between launches.  `done` tells the caller
+// whether the reduction kernel ran (the product was split) -- if not, S is the plain product and the caller runs its own kernels.
+constexpr int GEMM_DIST_PARTS = 32;
+struct GemmFusedReduce {
+  int mode;
+  double *dinv, *dist, *scratch;
+  int *counter;
+  bool done;
+};
 // `tickets`: GEMM_MAX_TICKETS zero-initialised ints owned by the caller (one stream at a time, like `work`); with them
 // a split-K product finishes inside the GEMM kernel (the last piece of a tile to arrive adds the partial planes in a
 // fixed order) instead of in a second launch.  The kernel leaves them zero.

@@ -961,13 +961,14 @@ __global__ void sym_scale_apply_kernel(double *__restrict__ S, int b, const doub
 
 // out[blk] = partial sums of |S - I|_F^2: DIST_BLOCKS blocks, fixed assignment and order (the host adds them)
 constexpr int DIST_BLOCKS = 32;
-__global__ __launch_bounds__(256) void dist_to_identity_kernel(const double *__restrict__ S, int b, double *__restrict__ out) {
+__global__ __launch_bounds__(256) void dist_to_identity_kernel(const double *__restrict__ S, int b, double *__restrict__ out,
+                                                               double diag = 1.0) {   // diag = 0: |S|_F^2
   __shared__ double red[256];
   double acc = 0.0;
   const long tot = (long)b * b;
   for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < tot; e += (long)DIST_BLOCKS * 256) {
     const int i = (int)(e % b), j = (int)(e / b);
-    const double d = S[e] - (i == j ? 1.0 : 0.0);
+    const double d = S[e] - (i == j ? diag : 0.0);
     acc = __builtin_fma(d, d, acc);
   }
   red[threadIdx.x] = acc;
@@ -987,10 +988,10 @@ __global__ void set_identity_kernel(double *__restrict__ M, int b) {
 
 // W(i,j) = rowscale[i] * Z(i,j)
 __global__ void row_scale_kernel(const double *__restrict__ Z, int b, const double *__restrict__ rowscale,
-                                 double *__restrict__ W) {
+                                 double *__restrict__ W, double pre = 1.0) {   // pre: a scalar factor applied first
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long)b * b) return;
-  W[e] = Z[e] * rowscale[(int)(e % b)];
+  W[e] = (pre * Z[e]) * rowscale[(int)(e % b)];
 }
 
 // res[j] = | Z(:,j) - theta_j Q(:,j) |_2 , j < K ; also column norms of Q when Z == nullptr
@@ -1099,6 +1100,8 @@ struct EigWork {
   double *lam, *scale, *res, *theta, *dinv, *gemm_ws, *apriori;   // res (b) and theta (b) are adjacent: one copy to the host
   int *perm, *flags;
   int *tickets;         // GEMM_MAX_TICKETS zeroed counters of the in-kernel split-K reduction (main stream only)
+  double *red;          // one double per 16 x 16 tile of a b x b matrix + an int counter (zero between launches): GemmFusedReduce
+  int *redcnt;
   size_t gemm_ws_elems;
 };
 
@@ -1160,6 +1163,7 @@ static size_t eig_workspace_bytes(int s, int K) {
   tot += 5 * align_up(sizeof(double) * (size_t)b) + align_up(sizeof(double) * 2 * APRIORI_BLOCKS);
   tot += align_up(sizeof(int) * (size_t)b) + align_up(sizeof(int) * 16) + align_up(sizeof(int) * GEMM_MAX_TICKETS);
   if (!dense) tot += align_up(sizeof(double) * eig_gemm_ws_elems(s, b));
+  if (!dense) tot += align_up(sizeof(double) * ((size_t)ceil_div(b, 16) * ceil_div(b, 16) + 2));
   if (!dense && s >= 1024) tot += bsg_workspace_bytes(s, b);   // (used from s = 1536 on by default; tunable)
   return tot + 1024;
 }
@@ -1374,6 +1378,13 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
   FLGP_HIP(hipMemsetAsync(w.tickets, 0, sizeof(int) * GEMM_MAX_TICKETS, st));
   w.gemm_ws_elems = dense ? 0 : eig_gemm_ws_elems(s, b);
   w.gemm_ws = dense ? nullptr : (double *)take(sizeof(double) * w.gemm_ws_elems);
+  w.red = nullptr; w.redcnt = nullptr;
+  if (!dense) {
+    const size_t nt2 = (size_t)ceil_div(b, 16) * ceil_div(b, 16);
+    w.red = (double *)take(sizeof(double) * (nt2 + 2));
+    w.redcnt = (int *)(w.red + nt2);
+    FLGP_HIP(hipMemsetAsync(w.redcnt, 0, sizeof(int), st));
+  }
   BsG bs;
   if (!dense && s >= std::max(1024, tuning("eig_bs_min_s", 1536)) && tuning("eig_blocksparse", 1)) {
     bsg_carve(bs, p, s, b);
@@ -1423,10 +1434,11 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
     return bsg_product(st, bs, Xt, b, alpha, beta, Et, gamma, E2t, out_t);
   };
   const double *t_q = nullptr, *t_z = nullptr;   // blocks whose transposes currently sit in bs.T[0], bs.T[1]
-  auto gram_small = [&](const double *Xa, const double *Xb, double *out) {  // out = Xa^T Xb   (b x b)
+  auto gram_small = [&](const double *Xa, const double *Xb, double *out, GemmFusedReduce *fr = nullptr) {  // out = Xa^T Xb   (b x b)
     return gemm_launch(st, b, b, s, 1.0, Xa, s, 1, Xb, 1, s, 0.0, nullptr, 0, 0, out, 1, b, w.gemm_ws,
-                       w.gemm_ws_elems, 0.0, nullptr, w.tickets);
+                       w.gemm_ws_elems, 0.0, nullptr, w.tickets, fr);
   };
+  const bool fuse_reduce = tuning("eig_fused_reduce", 1) != 0;   // the small-matrix kernels behind a Gram product inside its reduction
   auto rotate = [&](const double *Xin, const double *Wm, double *out) {  // out = Xin Wm   (s x b)(b x b)
     return gemm_launch(st, s, b, b, 1.0, Xin, 1, s, Wm, 1, b, 0.0, nullptr, 0, 0, out, 1, s, w.gemm_ws,
                        w.gemm_ws_elems, 0.0, nullptr, w.tickets);
@@ -1471,15 +1483,15 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
   double *dist_d = host_slots ? (double *)((char *)g_ctx->pinned_dev + dist_off) : nullptr;
   double *rt_h = (host_slots && 2 * b <= RT_SLOT_DOUBLES) ? (double *)((char *)g_ctx->pinned + rt_off) : nullptr;
   double *rt_d = rt_h ? (double *)((char *)g_ctx->pinned_dev + rt_off) : nullptr;
-  auto dist_to_identity = [&](const double *M, double *out) -> int {
+  auto dist_to_identity = [&](const double *M, double *out, double diag = 1.0) -> int {
     double part_own[DIST_BLOCKS];
     const double *part = part_own;
     if (dist_d) {
-      hipLaunchKernelGGL(dist_to_identity_kernel, dim3(DIST_BLOCKS), dim3(256), 0, st, M, b, dist_d);
+      hipLaunchKernelGGL(dist_to_identity_kernel, dim3(DIST_BLOCKS), dim3(256), 0, st, M, b, dist_d, diag);
       FLGP_TRY(check_launch("dist_to_identity_kernel"));
       part = dist_h;
     } else {
-      hipLaunchKernelGGL(dist_to_identity_kernel, dim3(DIST_BLOCKS), dim3(256), 0, st, M, b, w.res);
+      hipLaunchKernelGGL(dist_to_identity_kernel, dim3(DIST_BLOCKS), dim3(256), 0, st, M, b, w.res, diag);
       FLGP_TRY(check_launch("dist_to_identity_kernel"));
       FLGP_HIP(hipMemcpyAsync(part_own, w.res, sizeof(double) * DIST_BLOCKS, hipMemcpyDeviceToHost, st));
     }
@@ -1505,31 +1517,57 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
   hipLaunchKernelGGL(set_identity_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, w.Id, b);
   FLGP_TRY(check_launch("set_identity_kernel"));
   int ns_orths = 0, jac_orths = 0;
+  // the first step of the coupled iteration, where Z = I:  M = beta I + alpha Y (into Zout: it IS the next Z),  Yout = Y M
+  const bool ns_first = tuning("eig_ns_first_step", 1) != 0;
+  auto first_step = [&](const double *Yc_, double alpha, double beta, double *Zout, double *Yout) -> int {
+    hipLaunchKernelGGL(eig_axpby_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, alpha, Yc_, beta, w.Id, Zout, (long)b * b);
+    FLGP_TRY(check_launch("eig_axpby_kernel"));
+    return small_gemm(Yc_, Zout, 1.0, 0.0, nullptr, Yout);
+  };
+  static_assert(GEMM_DIST_PARTS == DIST_BLOCKS, "the fused reduction answers in the slots of dist_to_identity_kernel");
   auto orth = [&](const double *Yin, double *Qout, double *cond_out) -> int {
-    FLGP_TRY(gram_small(Yin, Yin, w.T));
-    hipLaunchKernelGGL(sym_scale_diag_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, st, w.T, b, w.dinv);
-    hipLaunchKernelGGL(sym_scale_apply_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, w.T, b, w.dinv);
-    FLGP_TRY(check_launch("sym_scale_kernel"));
     double delta = 0.0;
-    FLGP_TRY(dist_to_identity(w.T, &delta));
+    // S = D Y^T Y D and |I - S|_F: inside the reduction kernel of the split product (one launch instead of four)
+    GemmFusedReduce fr{1 | 4, w.dinv, dist_d ? dist_d : w.res, w.red, w.redcnt, false};
+    FLGP_TRY(gram_small(Yin, Yin, w.T, fuse_reduce ? &fr : nullptr));
+    if (fr.done) {
+      double part_own[DIST_BLOCKS];
+      const double *part = dist_d ? dist_h : part_own;
+      if (!dist_d) FLGP_HIP(hipMemcpyAsync(part_own, w.res, sizeof(double) * DIST_BLOCKS, hipMemcpyDeviceToHost, st));
+      FLGP_HIP(stream_wait(st));
+      double sum = 0.0;
+      for (int q = 0; q < DIST_BLOCKS; ++q) sum += part[q];
+      delta = std::sqrt(sum);
+    } else {
+      hipLaunchKernelGGL(sym_scale_diag_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, st, w.T, b, w.dinv);
+      hipLaunchKernelGGL(sym_scale_apply_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, w.T, b, w.dinv);
+      FLGP_TRY(check_launch("sym_scale_kernel"));
+      FLGP_TRY(dist_to_identity(w.T, &delta));
+    }
     if (delta < 0.1 * tuning("eig_ns_plain_below_x10", 45)) {  // |I - S|_F bounds the spectral norm from above, loosely: try, and watch it contract
                                                               // (measured at configs[2]: 3.6 contracted, 5.7 did not)
       // well-conditioned block: S^-1/2 by the coupled Newton-Schulz iteration -- b x b MFMA GEMMs only
       //   M = (3 I - Z Y)/2,  Y <- Y M,  Z <- M Z ;  Y -> S^1/2, Z -> S^-1/2   (|I - S| < 1)
       double *Yc = w.T, *Zc = w.JV, *Mm = w.W, *Yn = w.JB, *Zn = w.X2;
-      FLGP_HIP(hipMemcpyAsync(Zc, w.Id, sizeof(double) * (size_t)b * b, hipMemcpyDeviceToDevice, st));
+      // (Z_0 = I is never stored: the first step is M = (3 I - Y)/2, Y <- Y M, Z <- M -- one product instead of three)
+      if (!ns_first) FLGP_HIP(hipMemcpyAsync(Zc, w.Id, sizeof(double) * (size_t)b * b, hipMemcpyDeviceToDevice, st));
       // the error contracts quadratically, e <- (3/4) e^2 + O(e^3): run the predicted number of
       // iterations without talking to the host, then check once (|I - S|_F over-estimates e, so
       // the prediction errs on the safe side); a block that does not contract falls through to Jacobi
       // (|I - S|_F over-estimates the spectral norm that contracts: the prediction starts from 0.3 |I - S|_F -- over eight start
       //  blocks at configs[2] one to five steps fewer per orthonormalisation with the closing check still at rounding level,
       //  13.84 -> 13.70 ms; a prediction that falls short fails that check and the block takes the scaled iteration below)
-      int kmax = 2;
+      int kmax = tuning("eig_ns_extra", 2);   // steps beyond the predicted count (the closing check tests the LAST step's M, so one is inherent)
       for (double e = std::min(delta * 0.01 * tuning("eig_ns_e0_pct", 30), 0.95); e > 1e-17 && kmax < 40; ++kmax) e = (e < 0.5) ? 0.8 * e * e : 0.5 * e + 0.4 * e * e;
       bool ok = false;
       for (int k = 0; k < kmax; ++k) {
-        FLGP_TRY(small_gemm(Zc, Yc, -0.5, 1.5, w.Id, Mm));
-        FLGP_TRY(small_gemm2(Yc, Mm, Yn, Mm, Zc, Zn));
+        if (k == 0 && ns_first) {
+          FLGP_TRY(first_step(Yc, -0.5, 1.5, Zn, Yn));
+          if (kmax == 1) FLGP_HIP(hipMemcpyAsync(Mm, Zn, sizeof(double) * (size_t)b * b, hipMemcpyDeviceToDevice, st));   // (the closing check reads Mm)
+        } else {
+          FLGP_TRY(small_gemm(Zc, Yc, -0.5, 1.5, w.Id, Mm));
+          FLGP_TRY(small_gemm2(Yc, Mm, Yn, Mm, Zc, Zn));
+        }
         std::swap(Yc, Yn);
         std::swap(Zc, Zn);
       }
@@ -1572,19 +1610,17 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
       // Jacobi sweeps.  sigma = |S^2|_F^(1/2) over-estimates lambda_max by at most b^(1/4).
       double *Yc = w.T, *Zc = w.JV, *Mm = w.W, *Yn = w.JB, *Zn = w.X2;
       FLGP_TRY(small_gemm(Yc, Yc, 1.0, 0.0, nullptr, Yn));
-      hipLaunchKernelGGL(eig_axpby_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, 1.0, Yn, 1.0, w.Id, Mm,
-                         (long)b * b);   // Mm = S^2 + I, so that the distance-to-identity kernel returns |S^2|_F
-      FLGP_TRY(check_launch("eig_axpby_kernel"));
       // (sigma computed on the device -- one question to the host less, one launch more -- measured: 14.90 ms either way)
       double f2 = 0.0;
-      FLGP_TRY(dist_to_identity(Mm, &f2));
+      FLGP_TRY(dist_to_identity(Yn, &f2, 0.0));      // |S^2|_F
       const double sigma = 1.02 * std::sqrt(f2);
       if (sigma > 0.0 && std::isfinite(sigma)) {
         hipLaunchKernelGGL(eig_axpby_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, 1.0 / sigma, Yc, 0.0, w.Id,
                            Yn, (long)b * b);
         FLGP_TRY(check_launch("eig_axpby_kernel"));
         std::swap(Yc, Yn);
-        FLGP_HIP(hipMemcpyAsync(Zc, w.Id, sizeof(double) * (size_t)b * b, hipMemcpyDeviceToDevice, st));
+        bool z_is_identity = ns_first;      // Z_0 = I not stored until a step needs it (see first_step)
+        if (!z_is_identity) FLGP_HIP(hipMemcpyAsync(Zc, w.Id, sizeof(double) * (size_t)b * b, hipMemcpyDeviceToDevice, st));
         double dm = 1.0;
         double zn = 0.0;   // |Z - I|_F^2 + 1 >= 1/x_min: an upper bound of cond(S / sigma)
         bool zn_valid = false;
@@ -1604,18 +1640,29 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
             const bool plain = ell > 1.0 - 1e-9;
             if (plain && after++ >= tail) break;
             const double a = plain ? 1.0 : std::sqrt(3.0 / (1.0 + ell + ell * ell));
-            FLGP_TRY(small_gemm(Zc, Yc, -0.5 * a * a * a, 1.5 * a, w.Id, Mm));
-            FLGP_TRY(small_gemm2(Yc, Mm, Yn, Mm, Zc, Zn));
+            if (z_is_identity) {
+              FLGP_TRY(first_step(Yc, -0.5 * a * a * a, 1.5 * a, Zn, Yn));
+              z_is_identity = false;
+            } else {
+              FLGP_TRY(small_gemm(Zc, Yc, -0.5 * a * a * a, 1.5 * a, w.Id, Mm));
+              FLGP_TRY(small_gemm2(Yc, Mm, Yn, Mm, Zc, Zn));
+            }
             std::swap(Yc, Yn);
             std::swap(Zc, Zn);
             ell = std::min(1.0, 0.5 * a * ell * (3.0 - a * a * ell * ell));
             ++kdyn;
           }
+          if (kdyn == 1 && ns_first)   // (the only step was the first one: its M sits in Zc, not in Mm)
+            FLGP_HIP(hipMemcpyAsync(Mm, Zc, sizeof(double) * (size_t)b * b, hipMemcpyDeviceToDevice, st));
           if (kdyn) {
             FLGP_TRY(dist_to_identity2(Mm, Zc, &dm, &zn));      // (zn is wanted only if dm passes: asked in the same breath)
             ok = std::isfinite(dm) && dm < 1e-9;
             zn_valid = ok;
           }
+        }
+        if (z_is_identity) {   // (no scaled step ran)
+          FLGP_HIP(hipMemcpyAsync(Zc, w.Id, sizeof(double) * (size_t)b * b, hipMemcpyDeviceToDevice, st));
+          z_is_identity = false;
         }
         for (int k = 0; k < 72 && !ok && std::isfinite(dm); ++k) {
           FLGP_TRY(small_gemm(Zc, Yc, -0.5, 1.5, w.Id, Mm));
@@ -1631,9 +1678,8 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
         if (tuning("eig_verbose", 0) > 1) fprintf(stderr, "[flgp orth] scaled: delta=%.3e sigma=%.3e scaled steps=%d dm=%.2e %s\n", delta, sigma, kdyn, dm, ok ? "ok" : "FAILED");
         if (ok) {
           if (!zn_valid) FLGP_TRY(dist_to_identity(Zc, &zn));
-          hipLaunchKernelGGL(eig_axpby_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, 1.0 / std::sqrt(sigma),
-                             Zc, 0.0, w.Id, Zn, (long)b * b);
-          hipLaunchKernelGGL(row_scale_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, Zn, b, w.dinv, w.W);
+          hipLaunchKernelGGL(row_scale_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, Zc, b, w.dinv, w.W,
+                             1.0 / std::sqrt(sigma));      // W = D (Z / sqrt(sigma))
           FLGP_TRY(check_launch("row_scale_kernel"));
           if (cond_out) {
             *cond_out = 1.0 + zn * zn;
@@ -2039,9 +2085,12 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
     //      (Not after the a-priori filter of iteration 0: the start block is no Ritz basis, and projecting along its
     //      columns would take the block out of span p(G) Q.)
     if (!(it < skip_rr_n)) {
-      FLGP_TRY(gram_small(w.Qold, cur, w.T));
-      hipLaunchKernelGGL(mask_strict_upper_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, w.T, b);
-      FLGP_TRY(check_launch("mask_strict_upper_kernel"));
+      GemmFusedReduce fr{2, nullptr, nullptr, w.red, w.redcnt, false};   // the strict upper triangle, by the reduction kernel
+      FLGP_TRY(gram_small(w.Qold, cur, w.T, fuse_reduce ? &fr : nullptr));
+      if (!fr.done) {
+        hipLaunchKernelGGL(mask_strict_upper_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, w.T, b);
+        FLGP_TRY(check_launch("mask_strict_upper_kernel"));
+      }
       FLGP_TRY(gemm_launch(st, s, b, b, -1.0, w.Qold, 1, s, w.T, 1, b, 1.0, cur, 1, s, cur, 1, s, w.gemm_ws, w.gemm_ws_elems,
                            0.0, nullptr, w.tickets));
     }

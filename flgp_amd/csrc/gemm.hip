@@ -531,10 +531,90 @@ __global__ void splitk_reduce_kernel(GemmArgs g, int nsplit) {
   g.C[(size_t)i * g.c_is + (size_t)j * g.c_js] = o;
 }
 
+// The reduction of a split SQUARE product with the small-matrix work of the eigensolver folded in (GemmFusedReduce,
+// common.h).  One workgroup per 16 x 16 tile: the 32 diagonal sums it needs first (into LDS), then its elements.  The
+// distance partials: every tile leaves its sum in scratch[], the last tile to arrive (counter) adds them -- tile q into part
+// q mod 32, in ascending q -- so the result does not depend on the order the tiles ran in.
+__global__ __launch_bounds__(256) void splitk_reduce_sym_kernel(GemmArgs g, int nsplit, int mode, double *__restrict__ dinv,
+                                                                double *__restrict__ dist, double *__restrict__ scratch,
+                                                                int *__restrict__ counter) {
+  __shared__ double dg[32];
+  __shared__ double red[256];
+  __shared__ int last;
+  const int b = g.M, tid = threadIdx.x;
+  const int nt1 = (b + 15) / 16;
+  const int i0 = (blockIdx.x / nt1) * 16, j0 = (blockIdx.x % nt1) * 16;
+  // the planes of this thread's element and -- threads 0..31 -- of one diagonal element, four loads of each in flight
+  const int i = i0 + (tid >> 4), j = j0 + (tid & 15);
+  const bool live = i < b && j < b;
+  const int q = (tid < 16) ? i0 + tid : j0 + tid - 16;
+  const bool hasd = (mode & 1) && tid < 32 && q < b;
+  const size_t plane = (size_t)b * b;
+  const double *pe = g.part + (live ? (size_t)i * b + j : 0);
+  const double *pd = g.part + (hasd ? (size_t)q * b + q : 0);
+  double v = 0.0, dsum = 0.0;
+  int z = 0;
+  for (; z + 4 <= nsplit; z += 4) {
+    double e[4], dq[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      e[u] = live ? pe[(size_t)(z + u) * plane] : 0.0;
+      dq[u] = hasd ? pd[(size_t)(z + u) * plane] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) { v += e[u]; dsum += dq[u]; }      // fixed order
+  }
+  for (; z < nsplit; ++z) {
+    if (live) v += pe[(size_t)z * plane];
+    if (hasd) dsum += pd[(size_t)z * plane];
+  }
+  if ((mode & 1) && tid < 32) dg[tid] = dsum > 0.0 ? 1.0 / __builtin_sqrt(dsum) : 0.0;
+  __syncthreads();
+  double d2 = 0.0;
+  if (live) {
+    // (row, column) of the caller's matrix: whichever of (i, j) has the unit stride is the row of a column-major result
+    const bool j_is_row = g.c_js == 1;
+    const int row = j_is_row ? j : i, col = j_is_row ? i : j;
+    if (mode & 1) {
+      const double drow = j_is_row ? dg[16 + (tid & 15)] : dg[tid >> 4], dcol = j_is_row ? dg[tid >> 4] : dg[16 + (tid & 15)];
+      v = v * drow * dcol;
+      if (i == j) dinv[i] = dg[tid >> 4];
+    }
+    if ((mode & 2) && row >= col) v = 0.0;
+    g.C[(size_t)i * g.c_is + (size_t)j * g.c_js] = v;
+    const double df = v - (i == j ? 1.0 : 0.0);
+    d2 = df * df;
+  }
+  if (!(mode & 4)) return;
+  red[tid] = d2;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) red[tid] += red[tid + off];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    scratch[blockIdx.x] = red[0];
+    __threadfence();
+    last = (atomicAdd(counter, 1) == (int)gridDim.x - 1);
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  if (tid < GEMM_DIST_PARTS) {
+    double a = 0.0;
+    for (int q = tid; q < (int)gridDim.x; q += GEMM_DIST_PARTS)   // device-scope loads: the sums were written through other XCDs' L2
+      a += __longlong_as_double((long long)__hip_atomic_load((unsigned long long *)&scratch[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    dist[tid] = a;
+    __threadfence_system();   // (dist may be host memory)
+  }
+  if (tid == 0) *counter = 0;
+}
+
 int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double *A, long a_is, long a_ks,
                 const double *B, long b_ks, long b_js, double beta, const double *E, long e_is, long e_js,
                 double *C, long c_is, long c_js, double *work, size_t work_elems, double gamma,
-                const double *E2, int *tickets) {
+                const double *E2, int *tickets, GemmFusedReduce *fused) {
+  if (fused) fused->done = false;
   if (M <= 0 || N <= 0) return FLGP_OK;
   GemmArgs g;
   // orient so that the contiguous output dimension is the kernel's column dimension
@@ -551,7 +631,7 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
     g.E = E; g.e_is = e_is; g.e_js = e_js;
     g.C = C; g.c_is = c_is; g.c_js = c_js;
   }
-  g.tickets = (work && tuning("gemm_fused_reduce", 0)) ? tickets : nullptr;
+  g.tickets = (work && !fused && tuning("gemm_fused_reduce", 0)) ? tickets : nullptr;
   g.alpha = alpha; g.beta = beta; g.gamma = gamma;
   g.E2 = (gamma == 0.0) ? nullptr : E2;
   if (beta == 0.0) g.E = nullptr;
@@ -592,6 +672,14 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
   }
   FLGP_TRY(check_launch("gemm_f64_kernel"));
   if (!g.tickets && nsplit > 1) {
+    if (fused && g.M == g.N && alpha == 1.0 && !g.E && !g.E2 && (g.c_is == 1 || g.c_js == 1)) {
+      const int nt1 = ceil_div(g.M, 16);
+      hipLaunchKernelGGL(splitk_reduce_sym_kernel, dim3(nt1 * nt1), dim3(256), 0, st, g, nsplit, fused->mode, fused->dinv,
+                         fused->dist, fused->scratch, fused->counter);
+      FLGP_TRY(check_launch("splitk_reduce_sym_kernel"));
+      fused->done = true;
+      return FLGP_OK;
+    }
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div((long)g.M * g.N, 256)), dim3(256), 0, st, g, nsplit);
     FLGP_TRY(check_launch("splitk_reduce_kernel"));
   }
