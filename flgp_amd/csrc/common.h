@@ -113,7 +113,11 @@ inline int check_launch(const char *what) {
 int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double *A, long a_is, long a_ks,
                 const double *B, long b_ks, long b_js, double beta, const double *E, long e_is, long e_js,
                 double *C, long c_is, long c_js, double *work, size_t work_elems, double gamma,
-                const double *E2, int *tickets = nullptr, struct GemmFusedReduce *fused = nullptr);
+                const double *E2, int *tickets = nullptr, struct GemmFusedReduce *fused = nullptr,
+                const struct GemmPair *pair = nullptr);
+// `pair`: a second product C2 = alpha A2 B2 of the same shape and strides in the same launch (no E / E2, never split):
+// two of the solver's s x b rotations fill the chip where one leaves its fixed costs exposed.
+struct GemmPair { const double *A2, *B2; double *C2; };
 // Optional extra work for the split-K reduction kernel of a SQUARE product S (M == N, alpha = 1, no E / E2), so that the
 // eigensolver's small matrices need no kernels of their own behind the product:
 //   mode bit 0: S <- D S D with D = diag(1 / sqrt(S_jj)) (0 where S_jj <= 0), D stored in dinv;

@@ -1443,6 +1443,14 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
     return gemm_launch(st, s, b, b, 1.0, Xin, 1, s, Wm, 1, b, 0.0, nullptr, 0, 0, out, 1, s, w.gemm_ws,
                        w.gemm_ws_elems, 0.0, nullptr, w.tickets);
   };
+  // two rotations by the same W in one launch (the Ritz vectors and G times them)
+  const bool pair_rot = tuning("eig_pair_rotate", 1) != 0;
+  auto rotate2 = [&](const double *X1, const double *X2, const double *Wm, double *out1, double *out2) -> int {
+    if (!pair_rot) { FLGP_TRY(rotate(X1, Wm, out1)); return rotate(X2, Wm, out2); }
+    const GemmPair pr{X2, Wm, out2};
+    return gemm_launch(st, s, b, b, 1.0, X1, 1, s, Wm, 1, b, 0.0, nullptr, 0, 0, out1, 1, s, w.gemm_ws, w.gemm_ws_elems, 0.0,
+                       nullptr, nullptr, nullptr, &pr);
+  };
   // orthonormalise the columns of Yin into Qout ("SVQB" on the column-normalised block, so that
   // the widely different column norms a Chebyshev filter leaves behind do not enter the
   // conditioning of the Gram matrix); returns the condition estimate of the scaled Gram matrix
@@ -2011,8 +2019,7 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
       double *x[2]; int nx = 0;
       for (int q = 0; q < 3; ++q) if (trio[q] != cur) x[nx++] = trio[q];
       A = x[0]; B = x[1];
-      FLGP_TRY(rotate(w.Qold, w.W, A));   // A = Ritz vectors
-      FLGP_TRY(rotate(Z, w.W, B));        // B = G * Ritz vectors
+      FLGP_TRY(rotate2(w.Qold, Z, w.W, A, B));   // A = Ritz vectors, B = G * Ritz vectors
       FLGP_TRY(residuals(A, B, &rmax));
       top = std::max(theta[0], 1e-300);
       if (after_rr(rmax, top, true)) { converged = true; result = A; break; }
@@ -2045,8 +2052,7 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
           FLGP_TRY(jacobi_refine(st, w.T, b, K, w, lam, nullptr, sweeps, false));
         }
         FLGP_TRY(sorted_basis_dev(st, b, w));
-        FLGP_TRY(rotate(Q, w.W, A));   // A = Ritz vectors
-        FLGP_TRY(rotate(Z, w.W, B));   // B = G * Ritz vectors
+        FLGP_TRY(rotate2(Q, Z, w.W, A, B));   // A = Ritz vectors, B = G * Ritz vectors
         FLGP_TRY(residuals(A, B, &rmax));
         top = std::max(theta[0], 1e-300);
         if (after_rr(rmax, top, false)) { converged = true; result = A; break; }

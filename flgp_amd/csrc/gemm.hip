@@ -48,6 +48,9 @@ struct GemmArgs {
   // tile store their accumulators as planes of PLANE doubles in the thread order they are held in, take a ticket, and
   // the piece that arrives last adds the planes in ascending z (a fixed order: deterministic) and runs the epilogue.
   int *tickets;
+  // a second product of the same shape in the same launch (gridDim.y = 2): its own operands and result, everything else shared
+  const double *A2, *B2;
+  double *C2;
 };
 
 constexpr int PLANE = GB * GB;    // doubles per partial plane of one 128 x 128 tile
@@ -282,7 +285,14 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   const int ntm = (g.M + GB - 1) / GB, ntn = (g.N + GB - 1) / GB;
   const int nt = ntm * ntn;
   int bid = blockIdx.x;
-  {
+  const double *gA = g.A, *gB = g.B;
+  double *gC = g.C;
+  if (gridDim.y > 1) {   // two products: the bands run over both tile sets (workgroups go to the XCDs by their linear id)
+    const int lin = blockIdx.y * gridDim.x + blockIdx.x, nt2 = 2 * nt;
+    const int q = nt2 / 8, rem = nt2 % 8, xcd = lin % 8;
+    bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + lin / 8;
+    if (bid >= nt) { bid -= nt; gA = g.A2; gB = g.B2; gC = g.C2; }
+  } else {
     const int q = nt / 8, rem = nt % 8, xcd = bid % 8;
     bid = (xcd < rem ? xcd * (q + 1) : rem * (q + 1) + (xcd - rem) * q) + bid / 8;
   }
@@ -308,8 +318,8 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   if (ns < 0) ns = 0;
   auto kof = [&](int si) { return kbeg + si * GK; };
 
-  const Operand oa = make_operand<GBT>(g.A, g.a_is, g.a_ks, row0, g.M, tid);
-  const Operand ob = make_operand<GBT>(g.B, g.b_js, g.b_ks, col0, g.N, tid);
+  const Operand oa = make_operand<GBT>(gA, g.a_is, g.a_ks, row0, g.M, tid);
+  const Operand ob = make_operand<GBT>(gB, g.b_js, g.b_ks, col0, g.N, tid);
   d4 acc[MI][MI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi)
@@ -482,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void gemm_f64_kernel(GemmArgs g) {
   auto emit = [&](auto pl_c, auto he_c, auto he2_c, auto in_c) {
     constexpr bool PL = decltype(pl_c)::value, HE = decltype(he_c)::value, HE2 = decltype(he2_c)::value, IN = decltype(in_c)::value;
     const long cis = PL ? (long)g.N : g.c_is, cjs = PL ? 1L : g.c_js;
-    double *cb = (PL ? g.part + (size_t)zidx * g.M * g.N : g.C) + (size_t)ti0 * cis + (size_t)tj0 * cjs;
+    double *cb = (PL ? g.part + (size_t)zidx * g.M * g.N : gC) + (size_t)ti0 * cis + (size_t)tj0 * cjs;
     const double *eb = HE ? g.E + (size_t)ti0 * g.e_is + (size_t)tj0 * g.e_js : nullptr;
     const double *e2b = HE2 ? g.E2 + (size_t)ti0 * g.e_is + (size_t)tj0 * g.e_js : nullptr;
 #pragma unroll
@@ -613,8 +623,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_sym_kernel(GemmArgs g, int 
 int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double *A, long a_is, long a_ks,
                 const double *B, long b_ks, long b_js, double beta, const double *E, long e_is, long e_js,
                 double *C, long c_is, long c_js, double *work, size_t work_elems, double gamma,
-                const double *E2, int *tickets, GemmFusedReduce *fused) {
+                const double *E2, int *tickets, GemmFusedReduce *fused, const GemmPair *pair) {
   if (fused) fused->done = false;
+  if (pair && (E || E2 || fused)) { set_error("gemm: a paired product takes no E / E2 / fused reduction"); return FLGP_ERR_INVALID; }
   if (M <= 0 || N <= 0) return FLGP_OK;
   GemmArgs g;
   // orient so that the contiguous output dimension is the kernel's column dimension
@@ -624,14 +635,17 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
     g.B = A; g.b_ks = a_ks; g.b_js = a_is;
     g.E = E; g.e_is = e_js; g.e_js = e_is;
     g.C = C; g.c_is = c_js; g.c_js = c_is;
+    if (pair) { g.A2 = pair->B2; g.B2 = pair->A2; }
   } else {
     g.M = M; g.N = N; g.Kd = Kd;
     g.A = A; g.a_is = a_is; g.a_ks = a_ks;
     g.B = B; g.b_ks = b_ks; g.b_js = b_js;
     g.E = E; g.e_is = e_is; g.e_js = e_js;
     g.C = C; g.c_is = c_is; g.c_js = c_js;
+    if (pair) { g.A2 = pair->A2; g.B2 = pair->B2; }
   }
-  g.tickets = (work && !fused && tuning("gemm_fused_reduce", 0)) ? tickets : nullptr;
+  if (!pair) { g.A2 = g.B2 = nullptr; g.C2 = nullptr; } else g.C2 = pair->C2;
+  g.tickets = (work && !fused && !pair && tuning("gemm_fused_reduce", 0)) ? tickets : nullptr;
   g.alpha = alpha; g.beta = beta; g.gamma = gamma;
   g.E2 = (gamma == 0.0) ? nullptr : E2;
   if (beta == 0.0) g.E = nullptr;
@@ -643,7 +657,7 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
   // one partial plane: M x N doubles for the reduction kernel, whole 128 x 128 tiles for the in-kernel reduction
   const size_t per = g.tickets ? (size_t)ntiles * PLANE : (size_t)g.M * g.N;
   int nsplit = 1;
-  if (work && ntiles < 256 && Kd >= 8 * GK) {
+  if (work && !pair && ntiles < 256 && Kd >= 8 * GK) {
     nsplit = (gbt == 64 ? tuning("gemm_tile64_blocks", 256) : 512) / ntiles;
     // at least gemm_min_stages (default 5) stages per block: with fewer, the partial planes (and the reduction that
     // reads them back) cost more than the extra blocks gain -- the 256 x 256 x 5000 Gram products of the
@@ -667,8 +681,9 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
     ProfScope ps("gemm_f64_kernel", st, fl);
     // second record per shape class (large / medium / small) for the bench breakdown
     ProfScope ps2(fl > 5e9 ? "gemm_large" : (fl > 2e8 ? "gemm_medium" : "gemm_small"), st, fl);
-    if (gbt == 64) hipLaunchKernelGGL(gemm_f64_kernel<64>, dim3(ntiles, 1, nsplit), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL(gemm_f64_kernel<128>, dim3(ntiles, 1, nsplit), dim3(256), 0, st, g);
+    const int ny = pair ? 2 : 1;
+    if (gbt == 64) hipLaunchKernelGGL(gemm_f64_kernel<64>, dim3(ntiles, ny, nsplit), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL(gemm_f64_kernel<128>, dim3(ntiles, ny, nsplit), dim3(256), 0, st, g);
   }
   FLGP_TRY(check_launch("gemm_f64_kernel"));
   if (!g.tickets && nsplit > 1) {
@@ -716,6 +731,15 @@ extern "C" int flgp_dev_gemm(void *stream, int M, int N, int Kd, double alpha, c
   FLGP_REQUIRE(M >= 0 && N >= 0 && Kd >= 0 && A && B && C, "gemm: bad arguments");
   return gemm_launch((hipStream_t)stream, M, N, Kd, alpha, A, a_is, a_ks, B, b_ks, b_js, beta, E, e_is, e_js, C,
                      c_is, c_js, d_work, work_elems, 0.0, nullptr);
+}
+
+extern "C" int flgp_dev_gemm_pair(void *stream, int M, int N, int Kd, double alpha, const double *A, const double *A2, long a_is,
+                                  long a_ks, const double *B, const double *B2, long b_ks, long b_js, double *C, double *C2,
+                                  long c_is, long c_js) {
+  FLGP_REQUIRE(M >= 0 && N >= 0 && Kd >= 0 && A && B && C && A2 && B2 && C2, "gemm_pair: bad arguments");
+  const GemmPair pr{A2, B2, C2};
+  return gemm_launch((hipStream_t)stream, M, N, Kd, alpha, A, a_is, a_ks, B, b_ks, b_js, 0.0, nullptr, 0, 0, C, c_is, c_js,
+                     nullptr, 0, 0.0, nullptr, nullptr, nullptr, &pr);
 }
 
 extern "C" int flgp_dev_gather_rows(void *stream, const double *dV, int ld, const int *d_idx, int n0, int K,

@@ -27,3 +27,8 @@ for Kd in (16, 64, 256):
     run("rotate  (s x b)(b x b)", s, b, Kd, X, (1, s), W, (1, b), O, (1, s), True)
 for Kd in (16, 320, 1280, 5000):
     run("gram    (b x s)(s x b)", b, b, Kd, X, (s, 1), X, (1, s), T, (1, b), True)
+# per-stage cost of the rotation as a function of the number of row tiles (latency- or bandwidth-bound?)
+for M in (640, 1280, 2560, 5000, 10000, 20000):
+    Xm = torch.randn(b, M, dtype=torch.float64, device="cuda"); Om = torch.empty(b, M, dtype=torch.float64, device="cuda")
+    for Kd in (64, 256):
+        run("rotate rows=%d" % M, M, b, Kd, Xm, (1, M), W, (1, b), Om, (1, M), True)

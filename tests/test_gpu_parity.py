@@ -465,6 +465,27 @@ def test_gemm_f64(stages, M, N, Kd):
                     np.testing.assert_allclose(got, ref, rtol=0, atol=1e-11 * max(1.0, np.sqrt(Kd)))
 
 
+@pytest.mark.parametrize("M,N,Kd", [(5000, 256, 256), (333, 64, 40), (4100, 192, 192)])
+def test_gemm_pair_is_two_single_products(stages, M, N, Kd):
+    """Two products in one launch (the eigensolver's pair of rotations) are bit for bit the two single launches."""
+    rng = np.random.default_rng(M + Kd)
+    L = stages.L
+    st = torch.cuda.current_stream().cuda_stream
+    A1, A2 = (torch.from_numpy(rng.normal(size=(Kd, M))).cuda() for _ in range(2))       # column-major M x Kd
+    B1 = torch.from_numpy(rng.normal(size=(N, Kd))).cuda()                                  # column-major Kd x N
+    B2 = torch.from_numpy(rng.normal(size=(N, Kd))).cuda()
+    for Bsecond in (B1, B2):
+        C1, C2, R1, R2 = (torch.zeros((N, M), dtype=torch.float64, device="cuda") for _ in range(4))
+        _lib.check(L.flgp_dev_gemm_pair(st, M, N, Kd, 1.0, A1.data_ptr(), A2.data_ptr(), 1, M, B1.data_ptr(), Bsecond.data_ptr(), 1, Kd,
+                                        C1.data_ptr(), C2.data_ptr(), 1, M))
+        for A, B, R in ((A1, B1, R1), (A2, Bsecond, R2)):
+            _lib.check(L.flgp_dev_gemm(st, M, N, Kd, 1.0, A.data_ptr(), 1, M, B.data_ptr(), 1, Kd, 0.0, None, 0, 0, R.data_ptr(), 1, M, None, 0))
+        torch.cuda.synchronize()
+        assert torch.equal(C1, R1) and torch.equal(C2, R2)
+        ref = (A2.cpu().numpy().T @ Bsecond.cpu().numpy().T)
+        np.testing.assert_allclose(C2.cpu().numpy().T, ref, rtol=0, atol=1e-11 * np.sqrt(Kd))
+
+
 @pytest.mark.parametrize("s,K", [(60, 60), (200, 30), (300, 300), (900, 100), (2000, 100)])
 def test_eig_topk(stages, s, K):
     rng = np.random.default_rng(s + K)
