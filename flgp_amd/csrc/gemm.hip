@@ -682,7 +682,13 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
     // second record per shape class (large / medium / small) for the bench breakdown
     ProfScope ps2(fl > 5e9 ? "gemm_large" : (fl > 2e8 ? "gemm_medium" : "gemm_small"), st, fl);
     const int ny = pair ? 2 : 1;
-    if (gbt == 64) hipLaunchKernelGGL(gemm_f64_kernel<64>, dim3(ntiles, ny, nsplit), dim3(256), 0, st, g);
+    // unused dynamic LDS caps the workgroups the dispatcher may stack on one CU (experiment knob, KB)
+    const int pad_kb = (gbt == 64) ? tuning("gemm_lds_pad_kb", 0) : 0;
+    if (pad_kb > 0) {
+      static int attr_set = 0;
+      if (!attr_set) { FLGP_HIP(hipFuncSetAttribute((const void *)gemm_f64_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 112 * 1024)); attr_set = 1; }
+    }
+    if (gbt == 64) hipLaunchKernelGGL(gemm_f64_kernel<64>, dim3(ntiles, ny, nsplit), dim3(256), (size_t)pad_kb * 1024, st, g);
     else hipLaunchKernelGGL(gemm_f64_kernel<128>, dim3(ntiles, ny, nsplit), dim3(256), 0, st, g);
   }
   FLGP_TRY(check_launch("gemm_f64_kernel"));
