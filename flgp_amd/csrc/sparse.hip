@@ -123,11 +123,16 @@ __global__ __launch_bounds__(64) void csc_scatter_kernel(const int *__restrict__
 // needs; the LDS unit executes a wave's instructions in order, so pass k+1 sees pass k.
 constexpr int COLSUM_CHUNK = 1024;     // rows; FLGP_COLSUM_CHUNK of the oracle
 
+// WIN: the table holds the columns [w0, w0 + wn) of window blockIdx.y only (s beyond what LDS holds: the chunk is walked once
+// per window, entries of other windows are skipped -- the order inside a column is untouched)
+template <bool WIN>
 __global__ __launch_bounds__(64) void colsum_chunk_kernel(const int *__restrict__ ell_idx, const double *__restrict__ val,
-                                                          int n, int r, int s, int nbits, double *__restrict__ part) {
+                                                          int n, int r, int s, int nbits, double *__restrict__ part, int wmax) {
   extern __shared__ double bins[];
   const int lane = threadIdx.x;
-  for (int j = lane; j < s; j += 64) bins[j] = 0.0;
+  const int w0 = WIN ? (int)blockIdx.y * wmax : 0;
+  const int wn = WIN ? ((s - w0 < wmax) ? s - w0 : wmax) : s;
+  for (int j = lane; j < wn; j += 64) bins[j] = 0.0;
   __syncthreads();
   const long i0 = (long)blockIdx.x * COLSUM_CHUNK;
   const long i1 = (i0 + COLSUM_CHUNK < n) ? i0 + COLSUM_CHUNK : n;
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(64) void colsum_chunk_kernel(const int *__restrict_
     const long en = eb + 64 + lane;
     const int coln = (en < e1) ? ell_idx[en] : 0;
     const double vn = (en < e1) ? val[en] : 0.0;
-    const bool act = eb + lane < e1;
+    const bool act = eb + lane < e1 && (!WIN || (unsigned)(col - w0) < (unsigned)wn);
     unsigned long long m = __ballot(act);
     for (int b = 0; b < nbits; ++b) {
       const bool bit = (col >> b) & 1;
@@ -154,12 +159,12 @@ __global__ __launch_bounds__(64) void colsum_chunk_kernel(const int *__restrict_
     // most of the step: ~700 of its ~1200 cycles)
     for (int k = 0; __ballot(rank == k) != 0ull; ++k)
       if (rank == k)
-        __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)&bins[col], v);
+        __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)&bins[col - w0], v);
     col = coln; v = vn;
   }
   __syncthreads();
-  double *out = part + (size_t)blockIdx.x * s;
-  for (int j = lane; j < s; j += 64) out[j] = bins[j];
+  double *out = part + (size_t)blockIdx.x * s + w0;
+  for (int j = lane; j < wn; j += 64) out[j] = bins[j];
 }
 
 // colsum[j] = chunk totals added in chunk order, from 0.0
@@ -221,9 +226,10 @@ __global__ __launch_bounds__(256) void row_normalize_kernel(double *__restrict__
 // ----------------------------------------------------------------------------------------
 // Gram: one wave per column j1.  The wave owns row j1 of G in LDS (s doubles) and walks the column's entries in
 // ascending row order: every G(j1, j2) is summed in ascending row order -- deterministic, and identical to the oracle.
-// A row's r products go to r distinct bins, so one ds_add_f64 serves a whole row; consecutive rows of a column share
-// anchors (they all have j1, and usually more), so rows are applied one instruction after the other -- the LDS unit
-// executes a wave's instructions in order, which keeps the sums sequential without a round trip through registers.
+// A row's r products go to r distinct bins; consecutive rows of a column share anchors (they all have j1, and usually
+// more).  One ds_add_f64 serves a group of 64 / LPR rows: lanes that hit the same bin are applied in ascending lane order
+// (= ascending row), and the LDS unit executes a wave's instructions in order, so the sums stay sequential without a
+// round trip through registers (see the note at `apply` below).
 //
 // Where the time goes (round 2, scripts/ubench_ldsatomic.hip): a ds_add_f64 costs ~60 cycles per instruction per
 // wave whatever the number of active lanes, and four waves per CU get four times that throughput -- 2000 rows per
@@ -234,16 +240,19 @@ __global__ __launch_bounds__(256) void row_normalize_kernel(double *__restrict__
 // ----------------------------------------------------------------------------------------
 constexpr int GRAM_PF = 4;      // groups of rows whose loads are in flight together
 
-template <int LPR>
+// WIN: the wave owns the columns [w0, w0 + wn) of row j1 only (window blockIdx.y); products for other windows are skipped
+template <int LPR, bool WIN>
 __global__ __launch_bounds__(64) void gram_kernel(const int *__restrict__ ell_idx, const double *__restrict__ val,
                                                   int s, int r, double inv_r, const int *__restrict__ colptr,
-                                                  const int *__restrict__ pos, double *__restrict__ G, int ldg) {
+                                                  const int *__restrict__ pos, double *__restrict__ G, int ldg, int wmax) {
   extern __shared__ double acc[];
   constexpr int RPG = 64 / LPR;     // rows per group
   constexpr int NG = 64 / RPG;      // groups per block of 64 positions
   const int lane = threadIdx.x;
   const int j1 = blockIdx.x;
-  for (int j = lane; j < s; j += 64) acc[j] = 0.0;
+  const int w0 = WIN ? (int)blockIdx.y * wmax : 0;
+  const int wn = WIN ? ((s - w0 < wmax) ? s - w0 : wmax) : s;
+  for (int j = lane; j < wn; j += 64) acc[j] = 0.0;
   __syncthreads();
   const int sub = lane / LPR;       // which row of a group this lane serves
   const int a = lane % LPR;         // slot inside the row
@@ -271,12 +280,16 @@ __global__ __launch_bounds__(64) void gram_kernel(const int *__restrict__ ell_id
       o.vj = val[ee];
       return o;
     };
+    // ONE ds_add_f64 per group of RPG rows: lanes of different rows that hit the same bin (bin j1 always, usually more)
+    // are applied by the LDS unit in ascending lane order = ascending row, which is the oracle's order.  (Until round 4
+    // the source spelled this as RPG instructions, one row each; per thread that is the same program, the compiler had
+    // merged them all along, and with a window test in the condition it split them in another order -- 1 ulp off in 0.5 %
+    // of the entries.  The lane-order rule is what the bit-exact tests on all 1e6 rows of configs[2] have been checking.)
     auto apply = [&](const Grp &o) {
       const double prod = o.vj * o.v;
-#pragma unroll
-      for (int q = 0; q < RPG; ++q)
-        if (o.act && sub == q)
-          __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)&acc[o.j2], prod);
+      const bool on = o.act && (!WIN || (unsigned)(o.j2 - w0) < (unsigned)wn);
+      const int bin = on ? o.j2 - w0 : 0;
+      if (on) __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)&acc[bin], prod);
     };
     Grp cur[GRAM_PF], nxt[GRAM_PF];
 #pragma unroll
@@ -293,8 +306,8 @@ __global__ __launch_bounds__(64) void gram_kernel(const int *__restrict__ ell_id
     epos = epos_next;
   }
   __syncthreads();
-  double *out = G + (size_t)j1 * ldg;
-  for (int j = lane; j < s; j += 64) out[j] = acc[j];
+  double *out = G + (size_t)j1 * ldg + w0;
+  for (int j = lane; j < wn; j += 64) out[j] = acc[j];
 }
 
 // vectors(i,k) = (sum_a A(i,a) V(idx(i,a),k)) / sigma_k * scale ; sigma_k = sqrt(max(eig_k,0))
@@ -495,7 +508,7 @@ extern "C" int flgp_dev_csc_build(void *stream, const int *d_ell_idx, int n, int
   hipStream_t st = (hipStream_t)stream;
   const long nnz = (long)n * r;
   FLGP_REQUIRE(nnz < 2147483647L, "CSC: n*r = %ld does not fit int32 positions", nnz);
-  FLGP_REQUIRE(s >= 1 && s <= 32768, "CSC: kernels are built for s <= 32768 (got %d)", s);
+  FLGP_REQUIRE(s >= 1 && s <= FLGP_SMAX, "CSC: kernels are built for s <= %d (got %d)", FLGP_SMAX, s);
   FLGP_REQUIRE(work_bytes >= flgp_dev_csc_workspace(n, s, r), "CSC: workspace too small");
   const CscPlan p = csc_plan(nnz, s);
   int *hist = (int *)d_work;
@@ -517,6 +530,14 @@ extern "C" int flgp_dev_csc_build(void *stream, const int *d_ell_idx, int n, int
   return check_launch("csc_scatter_kernel");
 }
 
+// columns of a per-column table of doubles that one workgroup keeps in LDS: all s of them up to 20000 (what rounds 1-3 were
+// built for), windows of 16384 beyond (the kernels then walk their input once per window)
+static int lds_window(int s) {
+  const int forced = tuning("sparse_window", 0);      // tests: windows on small inputs
+  if (forced > 0 && forced < s) return forced;
+  return s <= 20000 ? s : 16384;
+}
+
 extern "C" size_t flgp_dev_colsum_workspace(int n, int s) {
   return sizeof(double) * (size_t)ceil_div(n > 0 ? n : 1, COLSUM_CHUNK) * (size_t)s + 256;
 }
@@ -524,16 +545,22 @@ extern "C" size_t flgp_dev_colsum_workspace(int n, int s) {
 extern "C" int flgp_dev_colsum(void *stream, const int *d_ell_idx, const double *d_ell_val, int n, int r, int s,
                                double *d_colsum, void *d_work, size_t work_bytes) {
   hipStream_t st = (hipStream_t)stream;
-  FLGP_REQUIRE(n >= 0 && r >= 1 && s >= 1 && s <= 20000, "colsum: kernels are built for s <= 20000 (got %d)", s);
+  FLGP_REQUIRE(n >= 0 && r >= 1 && s >= 1 && s <= FLGP_SMAX, "colsum: need 1 <= s <= %d (got %d)", FLGP_SMAX, s);
   FLGP_REQUIRE(work_bytes >= flgp_dev_colsum_workspace(n, s), "colsum: workspace too small");
   const int nchunks = ceil_div(n > 0 ? n : 1, COLSUM_CHUNK);
   int nbits = 1;
   while ((1 << nbits) < s) ++nbits;
-  const size_t lds = sizeof(double) * (size_t)s;
-  if (lds > 48 * 1024)
-    FLGP_HIP(hipFuncSetAttribute((const void *)colsum_chunk_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  const int wmax = lds_window(s);                    // s itself while a table of s doubles fits LDS
+  const size_t lds = sizeof(double) * (size_t)wmax;
+  const void *fn = wmax < s ? (const void *)colsum_chunk_kernel<true> : (const void *)colsum_chunk_kernel<false>;
+  if (lds > 48 * 1024) FLGP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   ProfScope ps("colsum_kernel", st, 12.0 * (double)n * r);
-  hipLaunchKernelGGL(colsum_chunk_kernel, dim3(nchunks), dim3(64), lds, st, d_ell_idx, d_ell_val, n, r, s, nbits, (double *)d_work);
+  if (wmax < s)
+    hipLaunchKernelGGL(colsum_chunk_kernel<true>, dim3(nchunks, ceil_div(s, wmax)), dim3(64), lds, st, d_ell_idx, d_ell_val, n, r, s,
+                       nbits, (double *)d_work, wmax);
+  else
+    hipLaunchKernelGGL(colsum_chunk_kernel<false>, dim3(nchunks), dim3(64), lds, st, d_ell_idx, d_ell_val, n, r, s, nbits,
+                       (double *)d_work, wmax);
   FLGP_TRY(check_launch("colsum_chunk_kernel"));
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3(ceil_div(s, 256)), dim3(256), 0, st, (const double *)d_work, nchunks, s, d_colsum);
   return check_launch("colsum_reduce_kernel");
@@ -563,18 +590,22 @@ extern "C" int flgp_dev_row_normalize(void *stream, double *d_ell_val, int n, in
 extern "C" int flgp_dev_gram(void *stream, const int *d_ell_idx, const double *d_ell_val, int n, int s, int r,
                              const int *d_colptr, const int *d_pos, double *dG, int ldg) {
   (void)n;
-  FLGP_REQUIRE(s >= 1 && s <= 20000, "Gram: kernel is built for s <= 20000 (got %d)", s);
+  FLGP_REQUIRE(s >= 1 && s <= FLGP_SMAX, "Gram: need 1 <= s <= %d (got %d)", FLGP_SMAX, s);
   FLGP_REQUIRE(r >= 1 && r <= FLGP_RMAX && ldg >= s, "Gram: bad r / ldg");
-  const size_t lds = sizeof(double) * (size_t)s;
-  const void *fn = r <= 16 ? (const void *)gram_kernel<16> : (const void *)gram_kernel<32>;
+  const int wmax = lds_window(s);
+  const size_t lds = sizeof(double) * (size_t)wmax;
+  const bool win = wmax < s;
+  const void *fn = r <= 16 ? (win ? (const void *)gram_kernel<16, true> : (const void *)gram_kernel<16, false>)
+                           : (win ? (const void *)gram_kernel<32, true> : (const void *)gram_kernel<32, false>);
   if (lds > 48 * 1024) FLGP_HIP(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   ProfScope ps("gram_kernel", (hipStream_t)stream, 12.0 * (double)n * r + 8.0 * (double)s * s);
-  if (r <= 16)
-    hipLaunchKernelGGL(gram_kernel<16>, dim3(s), dim3(64), lds, (hipStream_t)stream, d_ell_idx, d_ell_val, s, r, 1.0 / (double)r,
-                       d_colptr, d_pos, dG, ldg);
-  else
-    hipLaunchKernelGGL(gram_kernel<32>, dim3(s), dim3(64), lds, (hipStream_t)stream, d_ell_idx, d_ell_val, s, r, 1.0 / (double)r,
-                       d_colptr, d_pos, dG, ldg);
+  const dim3 grid(s, win ? ceil_div(s, wmax) : 1);
+#define GRAM_LAUNCH(LPRv, WINv)                                                                                                \
+  hipLaunchKernelGGL((gram_kernel<LPRv, WINv>), grid, dim3(64), lds, (hipStream_t)stream, d_ell_idx, d_ell_val, s, r,         \
+                     1.0 / (double)r, d_colptr, d_pos, dG, ldg, wmax)
+  if (r <= 16) { if (win) GRAM_LAUNCH(16, true); else GRAM_LAUNCH(16, false); }
+  else { if (win) GRAM_LAUNCH(32, true); else GRAM_LAUNCH(32, false); }
+#undef GRAM_LAUNCH
   return check_launch("gram_kernel");
 }
 

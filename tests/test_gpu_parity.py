@@ -423,6 +423,54 @@ def test_csc_colsum_gram_bit_exact(oracle, stages, n, d, s, r):
     np.testing.assert_array_equal(G, G.T)
 
 
+@pytest.mark.parametrize("n,d,s,r,window", [(3000, 3, 257, 7, 0), (3000, 3, 257, 7, 100), (5000, 4, 65, 20, 16), (2049, 3, 300, 1, 299), (2500, 2, 130, 18, 64)])
+def test_colsum_and_gram_by_column_windows(oracle, stages, n, d, s, r, window):
+    """Beyond s = 20000 the per-column tables of the column-sum and Gram kernels no longer fit LDS and are filled window by
+    window (16384 columns at a time).  Forced on small inputs here: the same bits as the oracle, window boundaries inside
+    rows and at a ragged last window."""
+    X, U0, U = make_case(n, d, s, r, seed=78)
+    ei, zn = oracle.cross_similarity(X, U, r, gl="normalized")
+    d_ei = torch.from_numpy(ei).cuda(); d_ev = torch.from_numpy(zn).cuda()
+    csc = stages.csc(d_ei, s)
+    stages.L.flgp_set_tuning(b"sparse_window", window)
+    try:
+        np.testing.assert_array_equal(stages.colsum(d_ei, d_ev, s).cpu().numpy(), oracle.colsum(ei, zn, s))
+        av, _ = oracle.scale_A(ei, zn, s)
+        c = stages.colsum(d_ei, d_ev, s)
+        stages.col_scale(d_ei, d_ev, c, None, 1)
+        np.testing.assert_array_equal(d_ev.cpu().numpy(), av)
+        G = stages.gram(d_ei, d_ev, csc).cpu().numpy()
+    finally:
+        stages.L.flgp_set_tuning(b"sparse_window", 0)
+    np.testing.assert_array_equal(G, oracle.gram(ei, av, s))
+
+
+def test_more_than_20000_anchors(oracle, stages):
+    """s = 20500 (rounds 1-3 refused s > 20000): column sums and the Gram matrix bit for bit the oracle's, and the path's
+    eigenpairs satisfy G v = lambda v on the device's own Gram matrix."""
+    n, d, s, r, K = 62000, 3, 20500, 3, 24
+    X, U0, U = make_case(n, d, s, r, seed=5)
+    ei, zn = oracle.cross_similarity(X, U, r, gl="normalized")
+    d_ei = torch.from_numpy(ei).cuda(); d_ev = torch.from_numpy(zn).cuda()
+    csc = stages.csc(d_ei, s)
+    np.testing.assert_array_equal(stages.colsum(d_ei, d_ev, s).cpu().numpy(), oracle.colsum(ei, zn, s))
+    av, _ = oracle.scale_A(ei, zn, s)
+    c = stages.colsum(d_ei, d_ev, s)
+    stages.col_scale(d_ei, d_ev, c, None, 1)
+    np.testing.assert_array_equal(d_ev.cpu().numpy(), av)
+    G = stages.gram(d_ei, d_ev, csc)
+    Go = oracle.gram(ei, av, s)
+    assert torch.equal(G.cpu(), torch.from_numpy(Go))
+    del Go
+    eig, V, info = stages.eig_topk(G, K)
+    R = G @ V.T - V.T * eig            # (the (K, s) tensor V is the column-major s x K block; G is symmetric)
+    assert float(R.abs().max()) <= 1e-9 * float(eig[0])
+    assert float((V @ V.T - torch.eye(K, dtype=torch.float64, device="cuda")).abs().max()) <= 1e-10
+    Z = api.cross_similarity_lae_cpp(X, U, r, "normalized")
+    ep = api.spectrum_from_Z_cpp(Z, K, True)
+    np.testing.assert_allclose(ep.values, np.sqrt(eig.cpu().numpy()), rtol=1e-9)
+
+
 @pytest.mark.parametrize("s", [1, 31, 32, 257, 1000])
 def test_sym_pack_unpack(stages, s):
     """exchange 3 sends the upper triangle of the Gram partials: pack / unpack are exact copies, and the unpacked
