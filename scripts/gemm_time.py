@@ -32,3 +32,14 @@ for M in (640, 1280, 2560, 5000, 10000, 20000):
     Xm = torch.randn(b, M, dtype=torch.float64, device="cuda"); Om = torch.empty(b, M, dtype=torch.float64, device="cuda")
     for Kd in (64, 256):
         run("rotate rows=%d" % M, M, b, Kd, Xm, (1, M), W, (1, b), Om, (1, M), True)
+# channel camping?  W with a padded leading dimension (2112 B / 2176 B between its columns instead of 2048 B)
+for ldw in (256, 264, 272, 288):
+    Wp = torch.randn(b, ldw, dtype=torch.float64, device="cuda")
+    run("rotate ldW=%d" % ldw, s, b, 256, X, (1, s), Wp, (1, ldw), O, (1, s), True)
+# and X with a padded leading dimension
+for lds_ in (5000, 5008, 5024, 5120):
+    Xp = torch.randn(b, lds_, dtype=torch.float64, device="cuda"); Op = torch.empty(b, lds_, dtype=torch.float64, device="cuda")
+    run("rotate ldX=%d" % lds_, s, b, 256, Xp, (1, lds_), W, (1, b), Op, (1, lds_), True)
+# W row-major (k contiguous becomes row contiguous for the kernel: the RC mapping instead of KC)
+Wt = torch.randn(b, b, dtype=torch.float64, device="cuda")
+run("rotate W row-major", s, b, 256, X, (1, s), Wt, (b, 1), O, (1, s), True)
