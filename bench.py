@@ -317,8 +317,8 @@ def main():
             if c2:
                 kernels[name] = {"launches": c2, "ms": ms2, "avg_launch_ms": ms2 / c2, "work": w2}
     headline = (n, d, s, args.r, args.K, args.m) == (1_000_000, 16, 5000, 10, 200, 1000)   # the shape BASELINE.json quotes
-    if roof and not headline:
-        roof["traffic"] = None      # the committed counter passes are of the headline shape only
+    if roof and not (headline and world == 1):
+        roof["traffic"] = None      # the committed counter passes are of the headline shape on one GPU only
     elif roof:
         try:   # HBM bytes per launch of that kernel, from the committed rocprofv3 PMC passes (profiles/)
             pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["hk_panel_kernel"]
