@@ -102,6 +102,8 @@ _SIGNATURES = {
                             P, c_int, P]),
     "flgp_dev_gemm": (c_int, [P, c_int, c_int, c_int, c_double, P, c_long, c_long, P, c_long, c_long,
                               c_double, P, c_long, c_long, P, c_long, c_long, P, c_size_t]),
+    "flgp_dev_rotate": (c_int, [P, c_int, c_int, c_double, P, P, P, c_double, P, P, P]),
+    "flgp_dev_gram_small": (c_int, [P, c_int, c_int, P, P, P, P, c_size_t]),
     "flgp_dev_gemm_pair": (c_int, [P, c_int, c_int, c_int, c_double, P, P, c_long, c_long, P, P, c_long, c_long, P, P, c_long, c_long]),
     "flgp_dev_gather_rows": (c_int, [P, P, c_int, P, c_int, c_int, P]),
     # row-sharded path behind the C ABI: communicators + sharded entry points

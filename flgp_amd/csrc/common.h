@@ -118,10 +118,20 @@ int gemm_launch(hipStream_t st, int M, int N, int Kd, double alpha, const double
 // `pair`: a second product C2 = alpha A2 B2 of the same shape and strides in the same launch (no E / E2, never split):
 // two of the solver's s x b rotations fill the chip where one leaves its fixed costs exposed.
 struct GemmPair { const double *A2, *B2; double *C2; };
+int gemm_reduce_square(hipStream_t st, int b, const double *part, int nsplit, double *C, GemmFusedReduce *fused);
+// The eigensolver's b x b Gram product out = Xa^T Xb (Xa, Xb: s x b column-major) on its own kernel (rot.hip): split over the
+// rows, planes reduced by gemm.hip's reduction kernels (with the fused extras).  false: not this shape, nothing was launched.
+bool gramk_applicable(int s, int b, const double *Xa, const double *Xb, size_t work_elems);
+int gramk_launch(hipStream_t st, int s, int b, const double *Xa, const double *Xb, double *out, double *work, size_t work_elems,
+                 GemmFusedReduce *fused);
+// The eigensolver's rotation out = alpha X W + beta E on its own kernel (rot.hip): W k-major, WT[k * b + j] = W(k, j)
+bool rot_applicable(int s, int b, const double *X, const double *X2, const double *WT, const double *out, const double *out2);
+int rot_launch(hipStream_t st, int s, int b, double alpha, const double *X, const double *X2, const double *WT, double beta,
+               const double *E, const double *E2, double *out, double *out2);
 // Optional extra work for the split-K reduction kernel of a SQUARE product S (M == N, alpha = 1, no E / E2), so that the
 // eigensolver's small matrices need no kernels of their own behind the product:
 //   mode bit 0: S <- D S D with D = diag(1 / sqrt(S_jj)) (0 where S_jj <= 0), D stored in dinv;
-//        bit 1: only the strictly upper triangle (row < column) of S is kept, the rest zero;
+//        bit 1: only the strictly upper triangle (row < column) of S is kept, the rest zero (bit 3: the strictly lower one);
 //        bit 2: |S - I|_F^2 (after bits 0 / 1) as GEMM_DIST_PARTS partial sums in a fixed order into dist[] (may be host memory).
 // `scratch` holds one double per 16 x 16 tile of S, `counter` one int that is zero between launches.  `done` tells the caller
 // whether the reduction kernel ran (the product was split) -- if not, S is the plain product and the caller runs its own kernels.

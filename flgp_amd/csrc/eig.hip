@@ -873,11 +873,11 @@ __global__ __launch_bounds__(1024) void small_sym_eig_kernel(const double *__res
 }
 
 // keep the strictly upper triangle (i < j) of the b x b matrix C, zero the rest
-__global__ void mask_strict_upper_kernel(double *__restrict__ C, int b) {
+__global__ void mask_strict_upper_kernel(double *__restrict__ C, int b, int lower = 0) {   // lower: keep i > j instead
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long)b * b) return;
   const int i = (int)(e % b), j = (int)(e / b);
-  if (i >= j) C[e] = 0.0;
+  if (lower ? i <= j : i >= j) C[e] = 0.0;
 }
 
 // V0 = blockdiag(I_K, Vg): identity with the g x g block Vg in its lower-right corner
@@ -920,14 +920,14 @@ __global__ void jac_values_kernel(const double *__restrict__ B, const double *__
 // W(i, j) = rowscale[i] * V(i, perm[j]) * scale[j]   (b x ncols)
 __global__ void permute_scale_kernel(const double *__restrict__ V, int ldv, int b, const int *__restrict__ perm,
                                      const double *__restrict__ scale, const double *__restrict__ rowscale,
-                                     int ncols, double *__restrict__ W, int ldw) {
+                                     int ncols, double *__restrict__ W, int ldw, int transposed = 0) {
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long)b * ncols) return;
   const int i = (int)(e % b), j = (int)(e / b);
   double v = V[(size_t)perm[j] * ldv + i];
   if (scale) v *= scale[j];
   if (rowscale) v *= rowscale[i];
-  W[(size_t)j * ldw + i] = v;
+  W[transposed ? (size_t)i * ldw + j : (size_t)j * ldw + i] = v;      // transposed: W k-major, for rot.hip
 }
 
 // Ritz values in descending order without the host: perm[rank] = j, sorted[rank] = lam[j], rank = number of values
@@ -988,10 +988,11 @@ __global__ void set_identity_kernel(double *__restrict__ M, int b) {
 
 // W(i,j) = rowscale[i] * Z(i,j)
 __global__ void row_scale_kernel(const double *__restrict__ Z, int b, const double *__restrict__ rowscale,
-                                 double *__restrict__ W, double pre = 1.0) {   // pre: a scalar factor applied first
+                                 double *__restrict__ W, double pre = 1.0, int transposed = 0) {   // pre: a scalar factor applied first
   const long e = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= (long)b * b) return;
-  W[e] = (pre * Z[e]) * rowscale[(int)(e % b)];
+  const int i = (int)(e % b), j = (int)(e / b);
+  W[transposed ? (size_t)i * b + j : (size_t)e] = (pre * Z[e]) * rowscale[i];      // transposed: W k-major, for rot.hip
 }
 
 // res[j] = | Z(:,j) - theta_j Q(:,j) |_2 , j < K ; also column norms of Q when Z == nullptr
@@ -1298,23 +1299,23 @@ static int jacobi_refine(hipStream_t st, const double *T, int b, int K, EigWork 
 }
 
 // W = JV(:, order), order = the eigenvalues in w.lam descending, all on the device: w.perm = order, w.theta = sorted values
-static int sorted_basis_dev(hipStream_t st, int b, EigWork &w) {
+static int sorted_basis_dev(hipStream_t st, int b, EigWork &w, int transposed = 0) {
   hipLaunchKernelGGL(ritz_sort_kernel, dim3(ceil_div(b, 256)), dim3(256), 0, st, w.lam, b, w.perm, w.theta);
   hipLaunchKernelGGL(permute_scale_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, w.JV, b, b, w.perm,
-                     (const double *)nullptr, (const double *)nullptr, b, w.W, b);
+                     (const double *)nullptr, (const double *)nullptr, b, w.W, b, transposed);
   return check_launch("ritz_sort_kernel");
 }
 
 // W = JV(:, order) * diag(scale), order = eigenvalues descending
 static int sorted_basis(hipStream_t st, const std::vector<double> &lam, const std::vector<double> *scale, int b,
-                        int ncols, EigWork &w, std::vector<int> &order, const double *d_rowscale = nullptr) {
+                        int ncols, EigWork &w, std::vector<int> &order, const double *d_rowscale = nullptr, int transposed = 0) {
   order.resize(b);
   for (int j = 0; j < b; ++j) order[j] = j;
   std::stable_sort(order.begin(), order.end(), [&](int x, int y) { return lam[x] > lam[y]; });
   FLGP_HIP(hipMemcpyAsync(w.perm, order.data(), sizeof(int) * ncols, hipMemcpyHostToDevice, st));
   if (scale) FLGP_HIP(hipMemcpyAsync(w.scale, scale->data(), sizeof(double) * ncols, hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(permute_scale_kernel, dim3(ceil_div((long)b * ncols, 256)), dim3(256), 0, st, w.JV, b, b,
-                     w.perm, scale ? w.scale : nullptr, d_rowscale, ncols, w.W, b);
+                     w.perm, scale ? w.scale : nullptr, d_rowscale, ncols, w.W, b, transposed);
   FLGP_TRY(check_launch("permute_scale_kernel"));
   FLGP_HIP(stream_wait(st));  // order / scale are host vectors that may die after return
   return FLGP_OK;
@@ -1435,11 +1436,16 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
   };
   const double *t_q = nullptr, *t_z = nullptr;   // blocks whose transposes currently sit in bs.T[0], bs.T[1]
   auto gram_small = [&](const double *Xa, const double *Xb, double *out, GemmFusedReduce *fr = nullptr) {  // out = Xa^T Xb   (b x b)
+    if (gramk_applicable(s, b, Xa, Xb, w.gemm_ws_elems)) return gramk_launch(st, s, b, Xa, Xb, out, w.gemm_ws, w.gemm_ws_elems, fr);
     return gemm_launch(st, b, b, s, 1.0, Xa, s, 1, Xb, 1, s, 0.0, nullptr, 0, 0, out, 1, b, w.gemm_ws,
                        w.gemm_ws_elems, 0.0, nullptr, w.tickets, fr);
   };
   const bool fuse_reduce = tuning("eig_fused_reduce", 1) != 0;   // the small-matrix kernels behind a Gram product inside its reduction
+  // The rotations run on their own kernel (rot.hip) where the shape allows; W is then kept k-major (`wt` = 1 tells its producers)
+  const bool use_rot = rot_applicable(s, b, w.Q, w.Y, w.W, w.Yp, w.Z) && rot_applicable(s, b, w.Qold, nullptr, w.T, w.Z, nullptr);
+  const int wt = use_rot ? 1 : 0;
   auto rotate = [&](const double *Xin, const double *Wm, double *out) {  // out = Xin Wm   (s x b)(b x b)
+    if (use_rot) return rot_launch(st, s, b, 1.0, Xin, nullptr, Wm, 0.0, nullptr, nullptr, out, nullptr);
     return gemm_launch(st, s, b, b, 1.0, Xin, 1, s, Wm, 1, b, 0.0, nullptr, 0, 0, out, 1, s, w.gemm_ws,
                        w.gemm_ws_elems, 0.0, nullptr, w.tickets);
   };
@@ -1447,6 +1453,7 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
   const bool pair_rot = tuning("eig_pair_rotate", 1) != 0;
   auto rotate2 = [&](const double *X1, const double *X2, const double *Wm, double *out1, double *out2) -> int {
     if (!pair_rot) { FLGP_TRY(rotate(X1, Wm, out1)); return rotate(X2, Wm, out2); }
+    if (use_rot) return rot_launch(st, s, b, 1.0, X1, X2, Wm, 0.0, nullptr, nullptr, out1, out2);
     const GemmPair pr{X2, Wm, out2};
     return gemm_launch(st, s, b, b, 1.0, X1, 1, s, Wm, 1, b, 0.0, nullptr, 0, 0, out1, 1, s, w.gemm_ws, w.gemm_ws_elems, 0.0,
                        nullptr, nullptr, nullptr, &pr);
@@ -1590,7 +1597,7 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
         if (!dist_d) FLGP_HIP(hipMemcpyAsync(part_own, w.res, sizeof(double) * DIST_BLOCKS, hipMemcpyDeviceToHost, st));
         FLGP_HIP(stream_mark(st));
         // Zc may live in JV or X2; the rotation needs diag(dinv) Z in W (Mm's buffer: read by the kernel above first)
-        hipLaunchKernelGGL(row_scale_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, Zc, b, w.dinv, w.W);
+        hipLaunchKernelGGL(row_scale_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, Zc, b, w.dinv, w.W, 1.0, wt);
         FLGP_TRY(check_launch("row_scale_kernel"));
         FLGP_TRY(rotate(Yin, w.W, Qout));
         FLGP_HIP(mark_wait());
@@ -1687,7 +1694,7 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
         if (ok) {
           if (!zn_valid) FLGP_TRY(dist_to_identity(Zc, &zn));
           hipLaunchKernelGGL(row_scale_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, Zc, b, w.dinv, w.W,
-                             1.0 / std::sqrt(sigma));      // W = D (Z / sqrt(sigma))
+                             1.0 / std::sqrt(sigma), wt);  // W = D (Z / sqrt(sigma))
           FLGP_TRY(check_launch("row_scale_kernel"));
           if (cond_out) {
             *cond_out = 1.0 + zn * zn;
@@ -1717,7 +1724,7 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
       sc[j] = 1.0 / std::sqrt(l);
     }
     if (cond_out) *cond_out = (lmin > 0.0) ? lmax / lmin : 1e300;
-    FLGP_TRY(sorted_basis(st, lam, &sc, b, b, w, order, w.dinv));
+    FLGP_TRY(sorted_basis(st, lam, &sc, b, b, w, order, w.dinv, wt));
     return rotate(Yin, w.W, Qout);
   };
 
@@ -2007,7 +2014,7 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
         FLGP_TRY(jacobi_refine(side.st, w.T, b, K, w, lam, &sweeps, nsw, false));
         sweeps = nsw;
       }
-      FLGP_TRY(sorted_basis_dev(side.st, b, w));       // order and W on the device: the host is not asked
+      FLGP_TRY(sorted_basis_dev(side.st, b, w, wt));   // order and W on the device: the host is not asked
       FLGP_HIP(hipEventRecord(side.ev, side.st));
       FLGP_HIP(hipMemcpyAsync(w.Qold, Q, sizeof(double) * (size_t)tot, hipMemcpyDeviceToDevice, st));
       if (soft_on && tuning("eig_soft_estimate", 1)) FLGP_TRY(residual_estimate(Q, Z, w.T));
@@ -2051,7 +2058,7 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
           if (last_m >= tuning("eig_sweeps2_from_m", 11)) sweeps = std::max(sweeps, 2);
           FLGP_TRY(jacobi_refine(st, w.T, b, K, w, lam, nullptr, sweeps, false));
         }
-        FLGP_TRY(sorted_basis_dev(st, b, w));
+        FLGP_TRY(sorted_basis_dev(st, b, w, wt));
         FLGP_TRY(rotate2(Q, Z, w.W, A, B));   // A = Ritz vectors, B = G * Ritz vectors
         FLGP_TRY(residuals(A, B, &rmax));
         top = std::max(theta[0], 1e-300);
@@ -2091,6 +2098,16 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
     //      (Not after the a-priori filter of iteration 0: the start block is no Ritz basis, and projecting along its
     //      columns would take the block out of span p(G) Q.)
     if (!(it < skip_rr_n)) {
+      if (use_rot) {
+        // T^T = cur^T Qold, strictly lower: the same sums (products commute), laid out k-major as rot.hip reads W
+        GemmFusedReduce fr{8, nullptr, nullptr, w.red, w.redcnt, false};
+        FLGP_TRY(gram_small(cur, w.Qold, w.T, fuse_reduce ? &fr : nullptr));
+        if (!fr.done) {
+          hipLaunchKernelGGL(mask_strict_upper_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, w.T, b, 1);
+          FLGP_TRY(check_launch("mask_strict_upper_kernel"));
+        }
+        FLGP_TRY(rot_launch(st, s, b, -1.0, w.Qold, nullptr, w.T, 1.0, cur, nullptr, cur, nullptr));
+      } else {
       GemmFusedReduce fr{2, nullptr, nullptr, w.red, w.redcnt, false};   // the strict upper triangle, by the reduction kernel
       FLGP_TRY(gram_small(w.Qold, cur, w.T, fuse_reduce ? &fr : nullptr));
       if (!fr.done) {
@@ -2099,6 +2116,7 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
       }
       FLGP_TRY(gemm_launch(st, s, b, b, -1.0, w.Qold, 1, s, w.T, 1, b, 1.0, cur, 1, s, cur, 1, s, w.gemm_ws, w.gemm_ws_elems,
                            0.0, nullptr, w.tickets));
+      }
     }
     // ---- orthonormalise the filtered block (B is free by now; twice if ill-conditioned)
     FLGP_TRY(orth(cur, B, &cond));

@@ -591,6 +591,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_sym_kernel(GemmArgs g, int 
       if (i == j) dinv[i] = dg[tid >> 4];
     }
     if ((mode & 2) && row >= col) v = 0.0;
+    if ((mode & 8) && row <= col) v = 0.0;
     g.C[(size_t)i * g.c_is + (size_t)j * g.c_js] = v;
     const double df = v - (i == j ? 1.0 : 0.0);
     d2 = df * df;
@@ -738,6 +739,30 @@ extern "C" int flgp_dev_gemm(void *stream, int M, int N, int Kd, double alpha, c
   return gemm_launch((hipStream_t)stream, M, N, Kd, alpha, A, a_is, a_ks, B, b_ks, b_js, beta, E, e_is, e_js, C,
                      c_is, c_js, d_work, work_elems, 0.0, nullptr);
 }
+
+// The reduction half of a split product on its own (rot.hip's Gram kernel writes the planes): C(ic, jc) = sum over planes of
+// part[z][jc][ic] for a column-major b x b result with leading dimension b, with the fused extras of GemmFusedReduce.
+namespace flgp {
+int gemm_reduce_square(hipStream_t st, int b, const double *part, int nsplit, double *C, GemmFusedReduce *fused) {
+  GemmArgs g;
+  g.M = b; g.N = b; g.Kd = 0;
+  g.A = g.B = nullptr; g.a_is = g.a_ks = g.b_ks = g.b_js = 0;
+  g.alpha = 1.0; g.beta = 0.0; g.gamma = 0.0;
+  g.E = g.E2 = nullptr; g.e_is = g.e_js = 0;
+  g.C = C; g.c_is = b; g.c_js = 1;            // kernel (i, j) = caller (column, row), as gemm_launch orients a column-major result
+  g.shift_edges = 0; g.ksplit_len = 0; g.part = const_cast<double *>(part); g.tickets = nullptr;
+  g.A2 = g.B2 = nullptr; g.C2 = nullptr;
+  if (fused) {
+    const int nt1 = ceil_div(b, 16);
+    hipLaunchKernelGGL(splitk_reduce_sym_kernel, dim3(nt1 * nt1), dim3(256), 0, st, g, nsplit, fused->mode, fused->dinv, fused->dist,
+                       fused->scratch, fused->counter);
+    fused->done = true;
+    return check_launch("splitk_reduce_sym_kernel");
+  }
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(ceil_div((long)b * b, 256)), dim3(256), 0, st, g, nsplit);
+  return check_launch("splitk_reduce_kernel");
+}
+}  // namespace flgp
 
 extern "C" int flgp_dev_gemm_pair(void *stream, int M, int N, int Kd, double alpha, const double *A, const double *A2, long a_is,
                                   long a_ks, const double *B, const double *B2, long b_ks, long b_js, double *C, double *C2,

@@ -534,6 +534,61 @@ def test_gemm_pair_is_two_single_products(stages, M, N, Kd):
         np.testing.assert_allclose(C2.cpu().numpy().T, ref, rtol=0, atol=1e-11 * np.sqrt(Kd))
 
 
+@pytest.mark.parametrize("s,b", [(5000, 256), (4098, 192), (64, 64), (1030, 128), (20000, 256)])
+def test_rotation_kernel_is_the_gemm_bit_for_bit(stages, s, b):
+    """csrc/rot.hip: the solver's s x b by b x b rotation on its own kernel -- the same k-ascending chain per element as the
+    general GEMM: identical bits, alone, as a pair, and in place with the E term (cur <- cur - Qold T)."""
+    rng = np.random.default_rng(s + b)
+    L = stages.L
+    st = torch.cuda.current_stream().cuda_stream
+    X1, X2, E = (torch.from_numpy(rng.normal(size=(b, s))).cuda() for _ in range(3))     # column-major s x b
+    # column-major W(k, j) lives at W_cm[k + j b]; the kernel wants WT[k b + j] = W(k, j): the row-major copy of W
+    W_cm = torch.from_numpy(rng.normal(size=(b, b))).cuda()        # tensor [j][k] == column-major W(k, j)
+    W_km = W_cm.t().contiguous()                                   # tensor [k][j] == WT
+    def gemm(Xt, alpha, beta, Et, out):
+        _lib.check(L.flgp_dev_gemm(st, s, b, b, alpha, Xt.data_ptr(), 1, s, W_cm.data_ptr(), 1, b, beta, Et.data_ptr() if Et is not None else None,
+                                   1, s, out.data_ptr(), 1, s, None, 0))
+    R1, R2, O1, O2 = (torch.zeros((b, s), dtype=torch.float64, device="cuda") for _ in range(4))
+    gemm(X1, 1.0, 0.0, None, R1); gemm(X2, 1.0, 0.0, None, R2)
+    _lib.check(L.flgp_dev_rotate(st, s, b, 1.0, X1.data_ptr(), None, W_km.data_ptr(), 0.0, None, O1.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert torch.equal(O1, R1)
+    O1.zero_()
+    _lib.check(L.flgp_dev_rotate(st, s, b, 1.0, X1.data_ptr(), X2.data_ptr(), W_km.data_ptr(), 0.0, None, O1.data_ptr(), O2.data_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(O1, R1) and torch.equal(O2, R2)
+    Ein, Eref = E.clone(), E.clone()
+    gemm(X1, -1.0, 1.0, Eref, Eref)                                # in place, as the de-contamination step does
+    _lib.check(L.flgp_dev_rotate(st, s, b, -1.0, X1.data_ptr(), None, W_km.data_ptr(), 1.0, Ein.data_ptr(), Ein.data_ptr(), None))
+    torch.cuda.synchronize()
+    assert torch.equal(Ein, Eref)
+    ref = X1.cpu().numpy().T @ W_cm.cpu().numpy().T
+    np.testing.assert_allclose(R1.cpu().numpy().T, ref, rtol=0, atol=1e-11 * np.sqrt(b))
+
+
+@pytest.mark.parametrize("s,b", [(5000, 256), (4098, 192), (256, 64), (1030, 128), (20000, 256), (777 * 2, 256)])
+def test_gram_kernel_of_the_solver(stages, s, b):
+    """csrc/rot.hip: the solver's b x b Gram product Xa^T Xb over s rows on its own kernel.  Same planes as the general GEMM's
+    split-K where the row ranges coincide (s = 5000, b = 256: bit for bit), rounding-level otherwise; ragged last ranges."""
+    rng = np.random.default_rng(s * 3 + b)
+    L = stages.L
+    st = torch.cuda.current_stream().cuda_stream
+    Xa, Xb = (torch.from_numpy(rng.normal(size=(b, s))).cuda() for _ in range(2))        # column-major s x b
+    work = torch.empty(64 * b * b, dtype=torch.float64, device="cuda")
+    O, R = (torch.zeros((b, b), dtype=torch.float64, device="cuda") for _ in range(2))
+    _lib.check(L.flgp_dev_gram_small(st, s, b, Xa.data_ptr(), Xb.data_ptr(), O.data_ptr(), work.data_ptr(), work.numel()))
+    _lib.check(L.flgp_dev_gemm(st, b, b, s, 1.0, Xa.data_ptr(), s, 1, Xb.data_ptr(), 1, s, 0.0, None, 0, 0, R.data_ptr(), 1, b,
+                               work.data_ptr(), work.numel()))
+    torch.cuda.synchronize()
+    ref = Xb.cpu().numpy() @ Xa.cpu().numpy().T            # tensor [jc][ic] of the column-major result
+    np.testing.assert_allclose(O.cpu().numpy(), ref, rtol=0, atol=1e-11 * np.sqrt(s))
+    if (s, b) == (5000, 256):
+        assert torch.equal(O, R)
+    _lib.check(L.flgp_dev_gram_small(st, s, b, Xa.data_ptr(), Xa.data_ptr(), O.data_ptr(), work.data_ptr(), work.numel()))
+    torch.cuda.synchronize()
+    assert torch.equal(O, O.t())                           # a Gram matrix of one block is symmetric bit for bit
+
+
 @pytest.mark.parametrize("s,K", [(60, 60), (200, 30), (300, 300), (900, 100), (2000, 100)])
 def test_eig_topk(stages, s, K):
     rng = np.random.default_rng(s + K)
