@@ -34,13 +34,14 @@ struct RotArgs {
 
 // TM = rows of X per tile: 64 (four waves of 32 x 32) or 32 (four waves of 16 x 32: twice the tiles, for a chip that 64-row
 // tiles leave unevenly loaded -- 5000 rows are 316 tiles of 64 on 256 CUs, and the kernel is MFMA-bound on the CUs with two)
-template <int TM, bool HAS_E>
-__global__ __launch_bounds__(256, 2) void rot_kernel(RotArgs g) {
+template <int TM, int GKR, bool HAS_E>
+__global__ __launch_bounds__(256, 2) void rot_kernel(RotArgs g) {   // (GKR: k depth of a stage)
   constexpr int MI = TM / 32;                        // 16-row pieces per wave
   constexpr int XLD = TM + 16;                       // LDS row stride of the X tile (doubles): the fragment rows fall on disjoint banks
-  constexpr int XP = TM / 2, XK = 256 / XP, XREP = ROT_GK / XK;   // load mapping of X: XP row pairs x XK k per pass, XREP passes
-  __shared__ double Xs[2][ROT_GK * XLD];
-  __shared__ double Ws[2][ROT_GK * ROT_LD];
+  constexpr int XP = TM / 2, XK = 256 / XP, XREP = GKR / XK;     // (GKR >= XK)
+  constexpr int WREP = GKR / 8;   // load mapping of X: XP row pairs x XK k per pass, XREP passes
+  __shared__ double Xs[2][GKR * XLD];
+  __shared__ double Ws[2][GKR * ROT_LD];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int s = g.s, b = g.b;
   const int ntm = b / 64, ntn = (s + TM - 1) / TM, nt = ntm * ntn;
@@ -65,15 +66,15 @@ __global__ __launch_bounds__(256, 2) void rot_kernel(RotArgs g) {
   const double *px = X + ix + (size_t)xkq * s;
   const double *pw = g.WT + (size_t)kq * b + j0 + l2;
   const size_t xstep = (size_t)XK * s, wstep = (size_t)8 * b;
-  rd2 rx[2][XREP], rw[2][4];                         // two register sets: stage st + 1 waits in one while stage st + 2 is fetched into the other
+  rd2 rx[2][XREP], rw[2][WREP];                         // two register sets: stage st + 1 waits in one while stage st + 2 is fetched into the other
   auto fetch = [&](auto set_c, int st) {
     constexpr int SET = decltype(set_c)::value;
-    const double *qx = px + (size_t)st * ROT_GK * s;
-    const double *qw = pw + (size_t)st * ROT_GK * b;
+    const double *qx = px + (size_t)st * GKR * s;
+    const double *qw = pw + (size_t)st * GKR * b;
 #pragma unroll
     for (int rep = 0; rep < XREP; ++rep) rx[SET][rep] = *(const rd2 *)(qx + rep * xstep);
 #pragma unroll
-    for (int rep = 0; rep < 4; ++rep) rw[SET][rep] = *(const rd2 *)(qw + rep * wstep);
+    for (int rep = 0; rep < WREP; ++rep) rw[SET][rep] = *(const rd2 *)(qw + rep * wstep);
   };
   auto put = [&](auto set_c, int buf) {
     constexpr int SET = decltype(set_c)::value;
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256, 2) void rot_kernel(RotArgs g) {
 #pragma unroll
     for (int rep = 0; rep < XREP; ++rep) *(rd2 *)(dx + rep * XK * XLD) = rx[SET][rep];
 #pragma unroll
-    for (int rep = 0; rep < 4; ++rep) *(rd2 *)(dw + rep * 8 * ROT_LD) = rw[SET][rep];
+    for (int rep = 0; rep < WREP; ++rep) *(rd2 *)(dw + rep * 8 * ROT_LD) = rw[SET][rep];
   };
 
   // ---- fragments: lane (fr, fk); the wave's (16 MI) x 32 part of the tile: rows wr.., columns wc..
@@ -94,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void rot_kernel(RotArgs g) {
     for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = rd4{0.0, 0.0, 0.0, 0.0};
 
   using std::integral_constant;
-  const int nst = b / ROT_GK;                        // even: b is a multiple of 64
+  const int nst = b / GKR;                        // even: b is a multiple of 64
   fetch(integral_constant<int, 0>{}, 0);
   fetch(integral_constant<int, 1>{}, 1);
   put(integral_constant<int, 0>{}, 0);
@@ -110,9 +111,9 @@ __global__ __launch_bounds__(256, 2) void rot_kernel(RotArgs g) {
     for (int mi = 0; mi < MI; ++mi) xb[0][mi] = xs[16 * mi];
     wa[0][0] = ws[0]; wa[0][1] = ws[16];
 #pragma unroll
-    for (int kk = 0; kk < ROT_GK / 4; ++kk) {
+    for (int kk = 0; kk < GKR / 4; ++kk) {
       const int q = kk & 1;
-      if (kk + 1 < ROT_GK / 4) {                     // the next k step's fragments are on their way while this one multiplies
+      if (kk + 1 < GKR / 4) {                     // the next k step's fragments are on their way while this one multiplies
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) xb[q ^ 1][mi] = xs[(kk + 1) * 4 * XLD + 16 * mi];
         wa[q ^ 1][0] = ws[(kk + 1) * 4 * ROT_LD]; wa[q ^ 1][1] = ws[(kk + 1) * 4 * ROT_LD + 16];
@@ -180,12 +181,15 @@ int rot_launch(hipStream_t st, int s, int b, double alpha, const double *X, cons
   const double fl = 2.0 * (double)s * b * b * np;
   ProfScope ps("gemm_f64_kernel", st, fl);
   ProfScope ps2("gemm_medium", st, fl);
-  if (tm32) {
-    if (g.E) hipLaunchKernelGGL((rot_kernel<32, true>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((rot_kernel<32, false>), grid, dim3(256), 0, st, g);
+  if (tm32 && tuning("eig_rot_gk16", 1)) {
+    if (g.E) hipLaunchKernelGGL((rot_kernel<32, 16, true>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((rot_kernel<32, 16, false>), grid, dim3(256), 0, st, g);
+  } else if (tm32) {
+    if (g.E) hipLaunchKernelGGL((rot_kernel<32, 32, true>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((rot_kernel<32, 32, false>), grid, dim3(256), 0, st, g);
   } else {
-    if (g.E) hipLaunchKernelGGL((rot_kernel<64, true>), grid, dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((rot_kernel<64, false>), grid, dim3(256), 0, st, g);
+    if (g.E) hipLaunchKernelGGL((rot_kernel<64, 32, true>), grid, dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((rot_kernel<64, 32, false>), grid, dim3(256), 0, st, g);
   }
   return check_launch("rot_kernel");
 }
