@@ -127,7 +127,8 @@ constexpr int COLSUM_CHUNK = 1024;     // rows; FLGP_COLSUM_CHUNK of the oracle
 // per window, entries of other windows are skipped -- the order inside a column is untouched)
 template <bool WIN>
 __global__ __launch_bounds__(64) void colsum_chunk_kernel(const int *__restrict__ ell_idx, const double *__restrict__ val,
-                                                          int n, int r, int s, int nbits, double *__restrict__ part, int wmax) {
+                                                          int n, int r, int s, int nbits, double *__restrict__ part, int wmax,
+                                                          int direct) {
   extern __shared__ double bins[];
   const int lane = threadIdx.x;
   const int w0 = WIN ? (int)blockIdx.y * wmax : 0;
@@ -137,6 +138,34 @@ __global__ __launch_bounds__(64) void colsum_chunk_kernel(const int *__restrict_
   const long i0 = (long)blockIdx.x * COLSUM_CHUNK;
   const long i1 = (i0 + COLSUM_CHUNK < n) ? i0 + COLSUM_CHUNK : n;
   const long e0 = i0 * r, e1 = i1 * r;
+  if (direct) {
+    // ONE ds_add_f64 per step of 64 entries: lanes that hit the same column are applied by the LDS unit in ascending lane
+    // order, which is the entries' order -- the rule gram_kernel's row groups rest on (bit-exact there and here on all 1e6
+    // rows of configs[2]); the LDS unit executes a wave's instructions in order, so step follows step.  Eight steps' loads
+    // are in flight (with one the wave -- alone on its SIMD: 977 chunks on 1024 SIMDs -- waited a memory latency per step).
+    constexpr int CU = 8;
+    for (long eb = e0; eb < e1; eb += 64 * CU) {
+      int cq[CU];
+      double vq[CU];
+#pragma unroll
+      for (int u = 0; u < CU; ++u) {
+        const long e = eb + 64 * u + lane;
+        const long ec = e < e1 ? e : e1 - 1;             // (unconditional loads: a valid address, masked below)
+        cq[u] = ell_idx[ec];
+        vq[u] = val[ec];
+      }
+#pragma unroll
+      for (int u = 0; u < CU; ++u) {
+        const bool on = eb + 64 * u + lane < e1 && (!WIN || (unsigned)(cq[u] - w0) < (unsigned)wn);
+        const int bin = on ? cq[u] - w0 : 0;
+        if (on) __builtin_amdgcn_ds_atomic_fadd_f64((__attribute__((address_space(3))) double *)&bins[bin], vq[u]);
+      }
+    }
+    __syncthreads();
+    double *outd = part + (size_t)blockIdx.x * s + w0;
+    for (int j = lane; j < wn; j += 64) outd[j] = bins[j];
+    return;
+  }
   const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
   // the next step's entries are loaded while this step's are ranked and added
   long e = e0 + lane;
@@ -557,10 +586,10 @@ extern "C" int flgp_dev_colsum(void *stream, const int *d_ell_idx, const double 
   ProfScope ps("colsum_kernel", st, 12.0 * (double)n * r);
   if (wmax < s)
     hipLaunchKernelGGL(colsum_chunk_kernel<true>, dim3(nchunks, ceil_div(s, wmax)), dim3(64), lds, st, d_ell_idx, d_ell_val, n, r, s,
-                       nbits, (double *)d_work, wmax);
+                       nbits, (double *)d_work, wmax, tuning("colsum_direct", 1));
   else
     hipLaunchKernelGGL(colsum_chunk_kernel<false>, dim3(nchunks), dim3(64), lds, st, d_ell_idx, d_ell_val, n, r, s, nbits,
-                       (double *)d_work, wmax);
+                       (double *)d_work, wmax, tuning("colsum_direct", 1));
   FLGP_TRY(check_launch("colsum_chunk_kernel"));
   hipLaunchKernelGGL(colsum_reduce_kernel, dim3(ceil_div(s, 256)), dim3(256), 0, st, (const double *)d_work, nchunks, s, d_colsum);
   return check_launch("colsum_reduce_kernel");
