@@ -202,7 +202,14 @@ __global__ void colsum_reduce_kernel(const double *__restrict__ part, int nchunk
   if (j >= s) return;
   double acc = 0.0;
   int c = 0;
-  for (; c + 8 <= nchunks; c += 8) {      // eight loads in flight, added in order
+  for (; c + 32 <= nchunks; c += 32) {    // 32 loads in flight, added in order (s / 256 workgroups: a few waves on the whole chip,
+    double p[32];                         //  every batch a memory latency -- with eight in flight 46 us for 977 chunks)
+#pragma unroll
+    for (int u = 0; u < 32; ++u) p[u] = part[(size_t)(c + u) * s + j];
+#pragma unroll
+    for (int u = 0; u < 32; ++u) acc += p[u];
+  }
+  for (; c + 8 <= nchunks; c += 8) {
     double p[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) p[u] = part[(size_t)(c + u) * s + j];
@@ -591,7 +598,7 @@ extern "C" int flgp_dev_colsum(void *stream, const int *d_ell_idx, const double 
     hipLaunchKernelGGL(colsum_chunk_kernel<false>, dim3(nchunks), dim3(64), lds, st, d_ell_idx, d_ell_val, n, r, s, nbits,
                        (double *)d_work, wmax, tuning("colsum_direct", 1));
   FLGP_TRY(check_launch("colsum_chunk_kernel"));
-  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(ceil_div(s, 256)), dim3(256), 0, st, (const double *)d_work, nchunks, s, d_colsum);
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3(ceil_div(s, 64)), dim3(64), 0, st, (const double *)d_work, nchunks, s, d_colsum);
   return check_launch("colsum_reduce_kernel");
 }
 
