@@ -323,7 +323,7 @@ template <int NLOC>
 __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B, double *__restrict__ V, int b,
                                                          int ldb, int nbc, int round, double tol,
                                                          int *__restrict__ flags, int local_sweeps,
-                                                         int cross_only, long long *__restrict__ trace) {
+                                                         int cross_only, long long *__restrict__ trace, int batched_load) {
   constexpr int WB = NLOC / 2;        // block-column width
   constexpr int NP = NLOC / 2;        // pairs per local round
   constexpr int NT16 = NLOC / 16;     // 16-wide tiles per side
@@ -355,7 +355,34 @@ __global__ __launch_bounds__(1024) void jac_block_kernel(double *__restrict__ B,
 
   // the way in: two rows per lane (16 bytes), half the vector-memory and LDS-write instructions (b, ldb and bp are even, the
   // matrices 16-byte aligned): 3.3 -> 2.9 us.  (The way out is apply_w's own.)
+  // (round 4: as a loop this was load -> s_waitcnt vmcnt(0) -> ds_write per 16 bytes, four memory latencies in a row -- the
+  //  panels were last written by other XCDs -- 3.4 of a visit's 26 us; now all of a wave's loads are issued, then stored)
   auto load_panel = [&](const double *M) {
+    constexpr int CPW = NLOC / 16;      // columns per wave
+    if (b <= 512 && batched_load) {
+      d2v tmp[CPW][4];
+#pragma unroll
+      for (int cc = 0; cc < CPW; ++cc) {
+        const int gc = gcol(wave + 16 * cc);
+        const double *src = M + (size_t)(gc < b ? gc : 0) * ldb;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = 2 * lane + 128 * q;
+          tmp[cc][q] = *(const d2v *)(src + (i < b ? i : b - 2));       // unconditional: a valid address, masked below
+        }
+      }
+#pragma unroll
+      for (int cc = 0; cc < CPW; ++cc) {
+        const int c = wave + 16 * cc;
+        const bool live = gcol(c) < b;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int i = 2 * lane + 128 * q;
+          if (i < b) *(d2v *)(P + (size_t)c * bp + i) = live ? tmp[cc][q] : d2v{0.0, 0.0};
+        }
+      }
+      return;
+    }
     for (int c = wave; c < NLOC; c += 16) {
       const int gc = gcol(c);
       for (int i = 2 * lane; i < b; i += 128)
@@ -1201,10 +1228,10 @@ static int jacobi_run(hipStream_t st, int b, EigWork &w, std::vector<double> &h_
         hipLaunchKernelGGL(jac_stream_kernel, dim3(p.nbc / 2), dim3(1024), 0, st, JB, JV, b, b, p.nbc, round, tol, w.flags);
       else if (p.nloc == 32)
         hipLaunchKernelGGL(jac_block_kernel<32>, dim3(p.nbc / 2), dim3(1024), p.lds, st, JB, JV, b, b, p.nbc, round,
-                           tol, w.flags, tuning("jacobi_local_sweeps", 1), cross, g_jac_trace);
+                           tol, w.flags, tuning("jacobi_local_sweeps", 1), cross, g_jac_trace, tuning("jacobi_batched_load", 1));
       else if (p.nloc == 16)
         hipLaunchKernelGGL(jac_block_kernel<16>, dim3(p.nbc / 2), dim3(1024), p.lds, st, JB, JV, b, b, p.nbc, round,
-                           tol, w.flags, tuning("jacobi_local_sweeps", 1), cross, g_jac_trace);
+                           tol, w.flags, tuning("jacobi_local_sweeps", 1), cross, g_jac_trace, tuning("jacobi_batched_load", 1));
       else
         hipLaunchKernelGGL(jac_round_kernel, dim3(p.nbc / 2), dim3(p.nt), p.lds, st, JB, JV, b, b, p.w, p.nbc,
                            round, tol, w.flags, 1);
