@@ -247,6 +247,8 @@ __global__ __launch_bounds__(1024) void bsg_lists_kernel(const int *__restrict__
                                                          int part_max, int slab_cap, int4 *__restrict__ parts_u,
                                                          int4 *__restrict__ parts, int *__restrict__ slab0) {
   __shared__ int over;
+  __shared__ int nk_s[1024];          // the list lengths, for the serial passes below (ntile <= 1024: s <= 65536): from global
+                                      // memory every one of their ~80 iterations was a dependent trip to L2
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) over = 0;
   for (int t = wave; t < ntile; t += 16) {
@@ -260,12 +262,12 @@ __global__ __launch_bounds__(1024) void bsg_lists_kernel(const int *__restrict__
             d ? n + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0)) : -1;
       n += __builtin_popcountll(m);
     }
-    if (lane == 0) nk[t] = n;
+    if (lane == 0) { nk[t] = n; nk_s[t] = n; }
   }
   __syncthreads();
   if (tid == 0) {
     int run = 0, mx = 0;
-    for (int t = 0; t < ntile; ++t) { off[t] = run; run += nk[t]; mx = nk[t] > mx ? nk[t] : mx; }
+    for (int t = 0; t < ntile; ++t) { off[t] = run; run += nk_s[t]; mx = nk_s[t] > mx ? nk_s[t] : mx; }
     off[ntile] = run;
     meta[BSG_M_TOTAL] = run;
     meta[BSG_M_MAXNK] = mx;
@@ -275,8 +277,8 @@ __global__ __launch_bounds__(1024) void bsg_lists_kernel(const int *__restrict__
   if (over) return;
   for (int t = tid; t < ntile; t += 1024) {
     int rank = 0;
-    const int mine = nk[t];
-    for (int u = 0; u < ntile; ++u) rank += (nk[u] > mine) || (nk[u] == mine && u < t);
+    const int mine = nk_s[t];
+    for (int u = 0; u < ntile; ++u) rank += (nk_s[u] > mine) || (nk_s[u] == mine && u < t);
     order[rank] = t;
   }
   for (int t = wave; t < ntile; t += 16) {
@@ -294,7 +296,7 @@ __global__ __launch_bounds__(1024) void bsg_lists_kernel(const int *__restrict__
     for (int pass = 0; pass < 2; ++pass) {
       int np = 0, nslab = 0;
       for (int t = 0; t < ntile; ++t) {
-        const int P = (cap > 0 && nk[t] > cap) ? (nk[t] + cap - 1) / cap : 1;
+        const int P = (cap > 0 && nk_s[t] > cap) ? (nk_s[t] + cap - 1) / cap : 1;
         np += P; nslab += (P > 1) ? P : 0;
       }
       if (np <= part_max && nslab <= slab_cap) break;
@@ -302,10 +304,10 @@ __global__ __launch_bounds__(1024) void bsg_lists_kernel(const int *__restrict__
     }
     int np = 0, nslab = 0, mxp = 0;
     for (int t = 0; t < ntile; ++t) {
-      const int P = (cap > 0 && nk[t] > cap) ? (nk[t] + cap - 1) / cap : 1;
+      const int P = (cap > 0 && nk_s[t] > cap) ? (nk_s[t] + cap - 1) / cap : 1;
       slab0[t] = (P > 1) ? nslab : -1;
       for (int q = 0; q < P; ++q) {
-        const int lo = (int)(((long)q * nk[t]) / P), hi = (int)(((long)(q + 1) * nk[t]) / P);
+        const int lo = (int)(((long)q * nk_s[t]) / P), hi = (int)(((long)(q + 1) * nk_s[t]) / P);
         parts_u[np + q] = make_int4(t, lo, hi - lo, q | (P << 16));
         mxp = (hi - lo > mxp) ? hi - lo : mxp;
       }

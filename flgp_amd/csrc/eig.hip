@@ -960,14 +960,22 @@ __global__ void permute_scale_kernel(const double *__restrict__ V, int ldv, int 
 // Ritz values in descending order without the host: perm[rank] = j, sorted[rank] = lam[j], rank = number of values
 // ahead of lam[j] (larger, or equal with a lower index: the order std::stable_sort gives)
 __global__ void ritz_sort_kernel(const double *__restrict__ lam, int b, int *__restrict__ perm, double *__restrict__ sorted) {
+  // (the values pass through LDS 256 at a time: as a loop over global memory every thread made b dependent trips to L2, 15 us at b = 256)
+  __shared__ double sl[256];
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= b) return;
-  const double mine = lam[j];
+  const double mine = j < b ? lam[j] : 0.0;
   int rank = 0;
-  for (int i = 0; i < b; ++i) {
-    const double v = lam[i];
-    rank += (v > mine) || (v == mine && i < j);
+  for (int i0 = 0; i0 < b; i0 += 256) {
+    __syncthreads();
+    if ((int)threadIdx.x < 256 && i0 + (int)threadIdx.x < b) sl[threadIdx.x] = lam[i0 + threadIdx.x];
+    __syncthreads();
+    const int cnt = (b - i0 < 256) ? b - i0 : 256;
+    for (int q = 0; q < cnt; ++q) {
+      const double v = sl[q];
+      rank += (v > mine) || (v == mine && i0 + q < j);
+    }
   }
+  if (j >= b) return;
   perm[rank] = j;
   sorted[rank] = mine;
 }
@@ -1031,6 +1039,7 @@ __global__ void resid_kernel(const double *__restrict__ Z, const double *__restr
   __shared__ double red[256];
   double acc = 0.0;
   const double th = Z ? theta[(size_t)j * tstride] : 0.0;
+#pragma unroll 8     // (eight iterations' loads in flight; the chain keeps its order)
   for (int i = threadIdx.x; i < s; i += blockDim.x) {
     const double q = Q[(size_t)j * ld + i];
     const double d = Z ? Z[(size_t)j * ld + i] - th * q : q;
@@ -1414,7 +1423,7 @@ static int eig_topk_impl(void *stream, const double *dG, int ldg, int s, int K, 
     FLGP_HIP(hipMemsetAsync(w.redcnt, 0, sizeof(int), st));
   }
   BsG bs;
-  if (!dense && s >= std::max(1024, tuning("eig_bs_min_s", 1536)) && tuning("eig_blocksparse", 1)) {
+  if (!dense && s >= std::max(1024, tuning("eig_bs_min_s", 1536)) && s <= 65536 && tuning("eig_blocksparse", 1)) {   // (65536: bsg_lists_kernel keeps one int per 64-anchor tile in LDS)
     bsg_carve(bs, p, s, b);
     if (g_ctx && g_ctx->pinned && tuning("eig_pinned_slots", 1))
       bsg_host_slots(bs, g_ctx->pinned, (char *)g_ctx->pinned + HOST_SMALL_BYTES, HOST_BIG_BYTES);
