@@ -589,7 +589,8 @@ def test_gram_kernel_of_the_solver(stages, s, b):
     assert torch.equal(O, O.t())                           # a Gram matrix of one block is symmetric bit for bit
 
 
-@pytest.mark.parametrize("s,K", [(60, 60), (200, 30), (300, 300), (900, 100), (2000, 100)])
+@pytest.mark.parametrize("s,K", [(60, 60), (200, 30), (300, 300), (900, 100), (2000, 100),
+                                 (1537, 90), (2050, 200), (1601, 40)])      # odd s: the general GEMM instead of csrc/rot.hip's kernels
 def test_eig_topk(stages, s, K):
     rng = np.random.default_rng(s + K)
     # PSD with a repeated top eigenvalue (three copies of 1) and a decaying tail, as the path produces
