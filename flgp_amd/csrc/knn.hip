@@ -225,7 +225,7 @@ __global__ __launch_bounds__(256) void knn_kernel(const double *__restrict__ X, 
 }
 
 // ------------------------------------------------------------------------------------------
-// k-NN with a matrix-core screen (round 2; d <= 16, r <= 16, 512 <= s < 65536).
+// k-NN with a matrix-core screen (round 2; d <= 16, r <= 16, 512 <= s <= 32768: a queue entry holds anchor / 8 in twelve bits).
 //
 // The r nearest anchors and their distances stay EXACT -- the oracle's fp64 chain, bit for bit -- but that chain is only
 // run for the dozen anchors per point that can matter.  The rest is decided by E^_j, a bf16x3 matrix-core evaluation of
@@ -334,12 +334,14 @@ __device__ __forceinline__ void screen_sweep(const uint4 *__restrict__ panel, co
           // the screen has no say about carry tau = +inf and zeroed operands, the panel is finite.
           const float m = fmaxf(fmaxf(fmaxf(acc[t][4 * g4], acc[t][4 * g4 + 1]), acc[t][4 * g4 + 2]), acc[t][4 * g4 + 3]);   // v_max3 + v_max
           if (__ballot(m >= tau[t])) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-              if (acc[t][4 * g4 + i] >= tau[t]) {       // cnt counts in bytes of queue stride; past QC entries: overwritten, and counted
-                *(unsigned short *)(qp + (cnt[t] & ((QC - 1) * 4 * PB))) = (unsigned short)(j0 + 8 * g4 + i);
-                cnt[t] += 4 * PB;
-              }
+            // ONE queue entry per group of four anchors: (group << 4) | which of the four passed.  (Until round 4 every
+            // candidate was an entry of its own: four compare / mask / store / count sequences on this path, which half of
+            // all groups of a wave enter.)  group = anchor / 8; the half kh of the queue says which four of the eight.
+            const unsigned mk = (acc[t][4 * g4] >= tau[t] ? 1u : 0u) | (acc[t][4 * g4 + 1] >= tau[t] ? 2u : 0u) |
+                                (acc[t][4 * g4 + 2] >= tau[t] ? 4u : 0u) | (acc[t][4 * g4 + 3] >= tau[t] ? 8u : 0u);
+            if (mk) {                                     // cnt counts in bytes of queue stride; past QC entries: overwritten, and counted
+              *(unsigned short *)(qp + (cnt[t] & ((QC - 1) * 4 * PB))) = (unsigned short)((((unsigned)j0 >> 3) + g4) << 4 | mk);
+              cnt[t] += 4 * PB;
             }
           }
         }
@@ -493,15 +495,24 @@ __global__ __launch_bounds__(256, 2) void knn_screen_kernel(const double *__rest
     return __builtin_fma(-2.0, acc, xxa) + un;
   };
   {
-    const int ctot = c0 + c1;
-    int p0 = 0, p1 = 0;
-    auto next = [&]() {          // the smaller head of the two queues (the lists are disjoint)
-      const int j0 = p0 < c0 ? (int)q[(p0 * 2 + 0) * PB + tid] : 0x7fffffff;
-      const int j1 = p1 < c1 ? (int)q[(p1 * 2 + 1) * PB + tid] : 0x7fffffff;
-      const bool first = j0 < j1;
-      p0 += first ? 1 : 0;
-      p1 += first ? 0 : 1;
-      return first ? j0 : j1;
+    // entries: (group of eight anchors << 4) | mask of the queue's four (half 0: anchors 8 g .. 8 g + 3, half 1: + 4 .. + 7)
+    int ctot = 0;
+    for (int e = 0; e < c0; ++e) ctot += __builtin_popcount((unsigned)q[(e * 2 + 0) * PB + tid] & 15u);
+    for (int e = 0; e < c1; ++e) ctot += __builtin_popcount((unsigned)q[(e * 2 + 1) * PB + tid] & 15u);
+    int p0 = 0, p1 = 0;          // entries taken from either queue
+    unsigned m0 = 0, m1 = 0;     // what is left of the entries in hand
+    int b0 = 0x7fffffff, b1 = 0x7fffffff;   // their first anchors
+    auto refill = [&]() {
+      if (!m0 && p0 < c0) { const unsigned e = q[(p0 * 2 + 0) * PB + tid]; m0 = e & 15u; b0 = (int)(e >> 4) * 8; ++p0; }
+      if (!m1 && p1 < c1) { const unsigned e = q[(p1 * 2 + 1) * PB + tid]; m1 = e & 15u; b1 = (int)(e >> 4) * 8 + 4; ++p1; }
+    };
+    auto next = [&]() {          // the next anchor in ascending order: the entry in hand with the smaller first anchor (the groups are disjoint)
+      refill();
+      const bool first = m0 && (!m1 || b0 < b1);
+      unsigned &mm = first ? m0 : m1;
+      const int bit = __builtin_ctz(mm | 16u);
+      mm &= mm - 1;
+      return (first ? b0 : b1) + bit;
     };
     double un[DP], unn = 0.0;
     int jn = 0;
@@ -934,7 +945,7 @@ extern "C" int flgp_dev_knn(void *stream, const double *dX, int n, int ldx, int 
   // kernel and the VALU kernel's three waves per SIMD hide its latencies better (d = 16: 6.7 vs 6.0 ms
   // per 1e6 points).  knn_mfma = 1 / 0 forces one or the other.
   // d <= 16, r <= 16, enough anchors for 32 groups of them: the matrix-core screen (knn_screen = 0 switches it off)
-  if (dpad <= 16 && r >= 2 && r <= 16 && s >= 512 && s < 65536 && tuning("knn_screen", 1) &&
+  if (dpad <= 16 && r >= 2 && r <= 16 && s >= 512 && s <= 32768 && tuning("knn_screen", 1) &&
       tuning("knn_mfma", -1) < 0 && variant == 0) {
 #define KNN_SCREEN_CASE(DPv, RCv) if (dpad == DPv && rcap == RCv) return launch_knn_screen<DPv, RCv>(KNN_ARGS);
     KNN_SCREEN_CASE(4, 4) KNN_SCREEN_CASE(4, 8) KNN_SCREEN_CASE(4, 16)
