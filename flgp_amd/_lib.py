@@ -85,6 +85,7 @@ _SIGNATURES = {
     "flgp_dev_colsum": (c_int, [P, P, P, c_int, c_int, c_int, P, P, c_size_t]),
     "flgp_dev_col_scale": (c_int, [P, P, P, c_int, c_int, P, P, c_int]),
     "flgp_dev_row_normalize": (c_int, [P, P, c_int, c_int]),
+    "flgp_dev_col_scale_row_normalize": (c_int, [P, P, P, c_int, c_int, P, P]),
     "flgp_dev_gram": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, c_int]),
     "flgp_dev_sym_pack": (c_int, [P, P, c_int, c_int, P]),
     "flgp_dev_sym_unpack": (c_int, [P, P, c_int, P, c_int]),

@@ -18,6 +18,8 @@ extern "C" int flgp_dev_anchor_rows(int s);
 extern "C" int flgp_dev_v_to_z(void *stream, const double *d_v, int r, double *d_z);
 extern "C" size_t flgp_dev_hk_workspace(int n0, int n1, int K, int gather0);
 extern "C" int flgp_dev_mean(void *stream, const double *d_x, long count, double *d_out, double *d_work);
+extern "C" int flgp_dev_col_scale_row_normalize(void *stream, const int *d_ell_idx, double *d_ell_val, int n, int r,
+                                                const double *d_colsum, const double *d_num_class);
 extern "C" int flgp_dev_se_weights_den(void *stream, const int *d_knn_idx, const double *d_knn_dist, int n, int ldk,
                                        int r, double den, int *d_ell_idx, double *d_ell_val);
 
@@ -234,8 +236,8 @@ int laplacian(Sim &S, hipStream_t st, int gl, const double *d_num_class) {
   if (gl != FLGP_GL_RW) {
     FLGP_TRY(colsum_of(S, st, S.ell_idx.as<int>(), S.ell_val.as<double>()));
     FLGP_TRY(flgp_comm_all_reduce_sum(S.comm, S.colsum.as<double>(), (size_t)S.s, st));            // exchange 2a
-    FLGP_TRY(flgp_dev_col_scale(st, S.ell_idx.as<int>(), S.ell_val.as<double>(), S.n, S.r, S.colsum.as<double>(),
-                                gl == FLGP_GL_CLUSTER_NORMALIZED ? d_num_class : nullptr, 0));
+    return flgp_dev_col_scale_row_normalize(st, S.ell_idx.as<int>(), S.ell_val.as<double>(), S.n, S.r, S.colsum.as<double>(),
+                                            gl == FLGP_GL_CLUSTER_NORMALIZED ? d_num_class : nullptr);     // one pass over the values
   }
   return flgp_dev_row_normalize(st, S.ell_val.as<double>(), S.n, S.r);
 }
@@ -1583,10 +1585,11 @@ static int se_grid_core(Sim &S, hipStream_t st0, int r, int K, const double *a2s
     const int *colptr = S.colptr.as<int>(), *pos = S.pos.as<int>();
     if (glc != FLGP_GL_RW) {
       FLGP_TRY(colsum_of(W, ws.s, eidx, W.ell_val.as<double>()));
-      FLGP_TRY(flgp_dev_col_scale(ws.s, eidx, W.ell_val.as<double>(), n, r, W.colsum.as<double>(),
-                                  glc == FLGP_GL_CLUSTER_NORMALIZED ? sizes : nullptr, 0));
+      FLGP_TRY(flgp_dev_col_scale_row_normalize(ws.s, eidx, W.ell_val.as<double>(), n, r, W.colsum.as<double>(),
+                                                glc == FLGP_GL_CLUSTER_NORMALIZED ? sizes : nullptr));
+    } else {
+      FLGP_TRY(flgp_dev_row_normalize(ws.s, W.ell_val.as<double>(), n, r));
     }
-    FLGP_TRY(flgp_dev_row_normalize(ws.s, W.ell_val.as<double>(), n, r));
     FLGP_TRY(colsum_of(W, ws.s, eidx, W.ell_val.as<double>()));
     FLGP_TRY(flgp_dev_col_scale(ws.s, eidx, W.ell_val.as<double>(), n, r, W.colsum.as<double>(), nullptr, 1));
     DevBuf G, eig, V, vals, vecs, ework, uwork;

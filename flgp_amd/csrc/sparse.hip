@@ -240,12 +240,27 @@ __global__ void col_scale_kernel(const int *__restrict__ ell_idx, double *__rest
 // 256 rows per workgroup, staged through LDS: the rows are r doubles apart, so a thread walking its own row in
 // global memory touched a different cache line than its neighbours on every load (measured: 4x the bytes fetched and
 // written); the block's 256 r values are one contiguous run, read and written back coalesced.
-__global__ __launch_bounds__(256) void row_normalize_kernel(double *__restrict__ val, int n, int r) {
+// With `idx` the column scaling of col_scale_kernel's mode 0 is applied on the way in (the same two or three rounded
+// multiplications per entry, then the same row sums): graphLaplacian_cpp's two passes over the values in one.
+__global__ __launch_bounds__(256) void row_normalize_kernel(double *__restrict__ val, int n, int r,
+                                                            const int *__restrict__ idx = nullptr,
+                                                            const double *__restrict__ colsum = nullptr,
+                                                            const double *__restrict__ num_class = nullptr) {
   extern __shared__ double rn_rows[];
   const long i0 = (long)blockIdx.x * 256;
   const int rows = (n - i0 < 256) ? (int)(n - i0) : 256;
   double *g = val + (size_t)i0 * r;
   const int cnt = rows * r;
+  if (idx) {
+    const int *gi = idx + (size_t)i0 * r;
+    for (int e = threadIdx.x; e < cnt; e += 256) {
+      const int j = gi[e];
+      double v = g[e];
+      v = v * (1.0 / (colsum[j] + 1e-9));              // src/Utils.cpp:201,204
+      if (num_class) v = v * num_class[j];             // src/Utils.cpp:205
+      rn_rows[e] = v;
+    }
+  } else
   for (int e = threadIdx.x; e < cnt; e += 256) rn_rows[e] = g[e];
   __syncthreads();
   if ((int)threadIdx.x < rows) {
@@ -620,6 +635,20 @@ extern "C" int flgp_dev_row_normalize(void *stream, double *d_ell_val, int n, in
     FLGP_HIP(hipFuncSetAttribute((const void *)row_normalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
   hipLaunchKernelGGL(row_normalize_kernel, dim3(ceil_div(n, 256)), dim3(256), lds, (hipStream_t)stream, d_ell_val,
                      n, r);
+  return check_launch("row_normalize_kernel");
+}
+
+// graphLaplacian_cpp's column scaling and row normalisation in one pass over the values (reference src/Utils.cpp:199-211):
+// the same operations per entry as flgp_dev_col_scale(mode 0) followed by flgp_dev_row_normalize, the same bits
+extern "C" int flgp_dev_col_scale_row_normalize(void *stream, const int *d_ell_idx, double *d_ell_val, int n, int r,
+                                                const double *d_colsum, const double *d_num_class) {
+  FLGP_REQUIRE(r >= 1 && r <= FLGP_RMAX && d_ell_idx && d_ell_val && d_colsum, "col_scale_row_normalize: bad arguments");
+  if (n == 0) return FLGP_OK;
+  const size_t lds = sizeof(double) * 256 * (size_t)r;
+  if (lds > 48 * 1024)
+    FLGP_HIP(hipFuncSetAttribute((const void *)row_normalize_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+  hipLaunchKernelGGL(row_normalize_kernel, dim3(ceil_div(n, 256)), dim3(256), lds, (hipStream_t)stream, d_ell_val, n, r, d_ell_idx,
+                     d_colsum, d_num_class);
   return check_launch("row_normalize_kernel");
 }
 
